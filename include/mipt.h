@@ -1,0 +1,234 @@
+/*
+ * mipt.h - C ABI of the MI355X path-tracing core.
+ *
+ * This is the drop-in boundary for ONE path of JohnLeber/CUDA-Path-Tracer: the
+ * render call that the reference exposes as CCUDAPathTracer::CalcRays
+ * (PathTracer.h:48-49, defined PathTracer.cu:556-771) and its CPU twin
+ * CCPUPathTracer::CalcRays (CPUPathTracer.h:17-18).  Everything here is plain
+ * C: fixed-width integers, plain pointers and sizes, no C++ or torch types.
+ *
+ * Conventions shared with the reference
+ *  - colour triples are BGR (.x = blue): MainFrm.cpp:247, RayTracerView.cpp:824-826
+ *  - matrices are row-major, row-vector convention (v' = v * M): PathTracer.cu:17-24
+ *  - the output image is (client_width/div) x (client_height/div), row-major,
+ *    3 floats per pixel holding 255*rgb: PathTracer.cu:550-552
+ *  - "number of samples" is the number of hemisphere samples at the FIRST hit;
+ *    deeper bounces use one sample: PathTracer.cu:447
+ *
+ * A global triangle id is the position of a triangle in the concatenation, in
+ * mesh order, of the triangle lists of all meshes with is_light == 0.
+ * Ties in the closest-hit search are broken towards the lowest id.
+ *
+ * Every function returns 0 on success and a negative MIPT_E_* code on failure;
+ * mipt_last_error() then returns a message for the calling thread.
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPT_OK            0
+#define MIPT_E_INVALID    -1   /* bad argument */
+#define MIPT_E_DEVICE     -2   /* HIP runtime error */
+#define MIPT_E_NOMEM      -3   /* host or device allocation failed */
+#define MIPT_E_LIMIT      -4   /* a size exceeds what the library supports */
+
+/* texel formats of mipt_material::tex_format / nml_format */
+#define MIPT_TEX_NONE   0
+#define MIPT_TEX_F32X3  1   /* 3 floats per texel, byte values 0..255 stored as float,
+                               .x = blue.  Layout of CUDAMaterial::pTexData,
+                               PathTracer.h:21, filled at RayTracerView.cpp:819-842 */
+#define MIPT_TEX_BGRA8  2   /* one uint32 per texel, byte0 = blue, byte1 = green,
+                               byte2 = red.  Layout of CTexture::m_pTexData,
+                               framework.h:78, filled at MainFrm.cpp:262-269 */
+
+/* One vertex of a triangle.  Replaces CCUDAVertex (PathTracer.h:12-17) and
+ * VBVertex (framework.h:66-70); same 32-byte layout. */
+typedef struct mipt_vertex {
+    float pos[3];
+    float normal[3];
+    float tex[2];
+} mipt_vertex;
+
+/* Replaces CUDAMaterial (PathTracer.h:19-28) / the texture members of CMesh
+ * (framework.h:130-136).  Pointers are HOST pointers owned by the caller. */
+typedef struct mipt_material {
+    const void* tex_data;
+    int32_t     tex_width;
+    int32_t     tex_height;
+    int32_t     tex_format;
+    int32_t     nml_format;
+    const void* nml_data;
+    int32_t     nml_width;
+    int32_t     nml_height;
+    float       diffuse[3];      /* BGR; used when the material has no texture */
+    int32_t     reserved;
+} mipt_material;
+
+/* Replaces the root CUDAMesh (PathTracer.h:30-39): a run of triangles that
+ * share one material.  Octree children of the reference's mesh tree are not
+ * part of the interface: the root always carries the full triangle list
+ * (RayTracerView.cpp:751-766) and the library builds its own BVH. */
+typedef struct mipt_mesh {
+    int64_t first_triangle;      /* index into mipt_scene_desc::vertices / 3 */
+    int64_t num_triangles;
+    int32_t material;            /* index into materials, -1 = none (pMaterial == 0) */
+    int32_t is_light;            /* CUDAMesh::bLight; such meshes are skipped, PathTracer.cu:261 */
+} mipt_mesh;
+
+typedef struct mipt_scene_desc {
+    const mipt_vertex*   vertices;       /* 3 * num_triangles entries */
+    int64_t              num_triangles;
+    const mipt_mesh*     meshes;
+    int32_t              num_meshes;
+    int32_t              num_materials;
+    const mipt_material* materials;
+} mipt_scene_desc;
+
+/* Camera scalars exactly as CalcRays receives them (PathTracer.cu:556):
+ * nClientWidth, nClientHeight, nDiv, P0 = Proj(0,0), P1 = Proj(1,1), ToLocal. */
+typedef struct mipt_camera {
+    int32_t client_width;
+    int32_t client_height;
+    int32_t div;
+    float   p0;
+    float   p1;
+    float   to_local[16];
+} mipt_camera;
+
+typedef struct mipt_params {
+    int32_t  num_samples;            /* nNumSamples, 1..10000 (RayTracerView.cpp:785-786) */
+    float    sun_pos[3];             /* nSunPos */
+    float    sun_intensity;          /* nSunIntensity, 3 in the reference (framework.h:99) */
+    int32_t  global_illumination;    /* bGlobalIllumination */
+    int32_t  use_textures;           /* bUseTextures */
+    int32_t  use_normals;            /* bUseNormals */
+    float    epsilon;                /* |det| threshold of the ray/triangle test: 1e-20 follows
+                                        xnacollision.cpp:1073-1076, 1e-5 follows PathTracer.cu:153 */
+    int32_t  normalize_normal_map;   /* 0 follows CPUPathTracer.cpp:315-317, 1 follows PathTracer.cu:314 */
+    uint32_t seed;                   /* key of the counter-based sample stream */
+    /* partition of the image and of the first-bounce sample loop over GPUs */
+    int32_t  shard_rank;             /* this process's index, 0..shard_count-1 */
+    int32_t  shard_count;            /* 0 or 1 = unsharded */
+    int32_t  tile_size;              /* edge of the square pixel tiles dealt round-robin; 0 = 32 */
+    int32_t  sample_begin;           /* first-bounce samples [sample_begin, sample_end) are */
+    int32_t  sample_end;             /* traced by this call; 0,0 = all num_samples */
+    int32_t  chunk_samples;          /* samples per wavefront pass, 0 = automatic */
+    int32_t  reserved;
+} mipt_params;
+
+typedef struct mipt_build_options {
+    int32_t sah_bins;                /* 0 = 16 */
+    int32_t max_leaf_triangles;      /* 0 = 4 */
+    float   traversal_cost;          /* 0 = 1.0 (in units of one triangle test) */
+    int32_t reserved;
+} mipt_build_options;
+
+typedef struct mipt_scene_info {
+    int64_t num_triangles;           /* non-light triangles in the BVH */
+    int64_t num_nodes;               /* inner nodes */
+    int64_t num_leaves;
+    int32_t max_depth;               /* deepest leaf; root = 0 */
+    int32_t num_materials;
+    int64_t geometry_bytes;          /* device bytes: nodes + triangle arrays + attributes */
+    int64_t texture_bytes;
+    double  build_ms;                /* device time of the BVH build */
+    double  upload_ms;               /* host flattening + H2D copies */
+    double  sah_cost;                /* SAH cost of the final tree */
+} mipt_scene_info;
+
+/* Device-side counters and timings of one mipt_frame_accumulate call. */
+typedef struct mipt_stats {
+    uint64_t closest_rays;           /* closest-hit queries issued */
+    uint64_t shadow_rays;            /* any-hit queries issued */
+    uint64_t node_visits;            /* BVH nodes fetched (both kinds of query) */
+    uint64_t triangle_tests;         /* ray/triangle tests executed */
+    uint64_t closest_node_visits;
+    uint64_t closest_triangle_tests;
+    uint64_t active_pixels;          /* pixels of this shard whose primary ray hit */
+    uint64_t reserved0;
+    double   closest_ms;             /* summed HIP-event time of the closest-hit kernel launches */
+    double   shadow_ms;              /* ... of the any-hit kernel launches */
+    double   shade_ms;               /* ... of ray generation, shading and resolve kernels */
+    double   total_ms;               /* HIP-event time of the whole call */
+    int32_t  closest_launches;
+    int32_t  shadow_launches;
+    int32_t  chunk_samples;          /* samples per pass actually used */
+    int32_t  reserved1;
+} mipt_stats;
+
+/* Replaces CPTCallback::UpdateProgress (PTProgress.h:3-7).  Called on the calling
+ * thread: first (0,total), then with a rising `done`, as PathTracer.cu:719-733. */
+typedef void (*mipt_progress_fn)(int64_t done, int64_t total, void* user);
+
+typedef struct mipt_scene mipt_scene;
+typedef struct mipt_frame mipt_frame;
+
+/* Selects the HIP device for this process (PathTracer.cu:577 hard-codes 0). */
+int mipt_init(int32_t device);
+const char* mipt_last_error(void);
+int mipt_device_name(char* buf, int32_t buflen);
+
+/* Flattens the scene, uploads it once and builds the SAH BVH on the GPU.
+ * Replaces the per-call deep copy of PathTracer.cu:593-677 (CopyMesh :466-499)
+ * and the octree of Mesh.cpp:88-166. */
+int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt, mipt_scene** out);
+void mipt_scene_destroy(mipt_scene* scene);
+int mipt_scene_get_info(const mipt_scene* scene, mipt_scene_info* out);
+
+/* Copies the finished BVH to host memory for validation.  nodes: 16 floats per
+ * node slot (num_node_slots of them), tri_v0/e1/e2: 4 floats per leaf slot. */
+int mipt_scene_bvh_sizes(const mipt_scene* scene, int64_t* num_node_slots, int64_t* num_leaf_slots,
+                         uint32_t* root_code);
+int mipt_scene_download_bvh(const mipt_scene* scene, float* nodes, float* tri_v0, float* tri_e1,
+                            float* tri_e2);
+
+/* Closest-hit / any-hit queries for caller-supplied rays (host arrays, 6 floats
+ * per ray: origin, direction).  This is the search of TraceRays, PathTracer.cu:
+ * 244-288 / CCPUPathTracer::Trace, CPUPathTracer.cpp:251-285, without shading.
+ * out_tri[i] = global triangle id or -1; out_tuv = 3 floats per ray (t, ua, va);
+ * out_any[i] = 1 if any triangle is hit with t >= 0 (the bHitOnly result). */
+int mipt_trace_rays(mipt_scene* scene, const float* rays, int64_t num_rays, float epsilon,
+                    int32_t* out_tri, float* out_tuv, uint8_t* out_any);
+
+/* Work buffers for one image size; reused across calls so that a render call
+ * allocates nothing. */
+int mipt_frame_create(mipt_scene* scene, const mipt_camera* cam, const mipt_params* params,
+                      mipt_frame** out);
+void mipt_frame_destroy(mipt_frame* frame);
+int mipt_frame_set_params(mipt_frame* frame, const mipt_camera* cam, const mipt_params* params);
+
+/* Traces this shard's part of the image.  d_accum is a DEVICE buffer of
+ * 3 floats per pixel that receives the unclamped first-bounce sum
+ * sum_n r1_n * L1_n / pdf of PathTracer.cu:449-451 (zero for pixels of other
+ * shards), ready for a sum-reduce across GPUs. */
+int mipt_frame_accumulate(mipt_frame* frame, float* d_accum, mipt_stats* stats,
+                          mipt_progress_fn progress, void* user);
+/* Applies PathTracer.cu:453-462 and :550-552 to the reduced sums: d_out (DEVICE,
+ * 3 floats per pixel) = 255 * min(1, (direct + I * sum / N) * albedo / pi). */
+int mipt_frame_finalize(mipt_frame* frame, const float* d_accum, float* d_out_bgr255);
+/* Primary-hit triangle ids of the last accumulate call (HOST buffer, one per pixel). */
+int mipt_frame_primary_ids(mipt_frame* frame, int32_t* out_tri);
+int64_t mipt_frame_num_pixels(const mipt_frame* frame);
+
+/* Whole render with host buffers: the body of CCUDAPathTracer::CalcRays
+ * (PathTracer.cu:556-771) for a prepared scene.  out_bgr255: 3 floats per pixel. */
+int mipt_render(mipt_scene* scene, const mipt_camera* cam, const mipt_params* params,
+                float* out_bgr255, int32_t* out_primary_tri, mipt_stats* stats,
+                mipt_progress_fn progress, void* user);
+
+/* Device memory helpers for hosts that have no allocator of their own. */
+int mipt_device_alloc(void** out, int64_t bytes);
+int mipt_device_free(void* p);
+int mipt_copy_to_host(void* dst, const void* d_src, int64_t bytes);
+int mipt_copy_to_device(void* d_dst, const void* src, int64_t bytes);
+int mipt_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */
