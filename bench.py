@@ -1,0 +1,192 @@
+"""Headline benchmark: Mrays/s of the wavefront path tracer on the Crytek-Sponza workload
+(direct + GI, 128 first-bounce samples, 1920x1080), one process per GPU.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one whole frame: every rank traces its image tiles (round-robin 32x32 tiles, all 128
+samples), the per-pixel first-bounce sums are reduced to rank 0 over RCCL and rank 0 applies the
+final clamp.  The Sponza meshes are not part of the reference tree, so the scene is the
+harness's procedural atrium with the same triangle count, material count and texture sizes
+(labelled synthetic in the output).  Rays are counted on the device (closest-hit + shadow
+queries actually issued).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cuda-path-tracer_amd"))
+
+WORKLOADS = {
+    # name: (scene kind, triangles, texture edge, samples, gi, width, height, div)
+    "crytek_gi128_1080p": ("crytek", 262000, 1024, 128, 1, 1920, 1080, 1),
+    "sponza_gi128_1080p": ("sponza", 66000, 1024, 128, 1, 1920, 1080, 1),
+    "sponza_direct_1080p": ("sponza", 66000, 1024, 64, 0, 1920, 1080, 1),
+    "crytek_gi16_270p": ("crytek", 262000, 256, 16, 1, 1920, 1080, 4),
+}
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet, packed fp32 FMA
+HBM_PEAK_GBS = 8000.0
+FLOP_PER_TRI_TEST = 51              # full Moeller-Trumbore from three vertices
+FLOP_PER_BOX_TEST = 22
+BYTES_PER_NODE = 64                 # one node record = the boxes of both children + links
+BYTES_PER_TRI_TEST = 36             # three float3 positions
+
+
+def cpu_baseline(scene, cam, params, budget_s=15.0):
+    """The CPU oracle (the restated reference CPU path with its octree) on this host's cores, on a
+    bounded sample of image rows of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    osc = ob.OracleScene(scene.desc)
+    w, h = cam.image_size
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # calibrate on a few rows, then size the sample to the time budget
+    probe_step = max(1, h // 4)
+    _, _, _, st = osc.render(cam, params, accel=ob.ACCEL_OCTREE, row_step=probe_step, row_phase=probe_step // 2, threads=threads)
+    rows_probe = len(range(probe_step // 2, h, probe_step))
+    per_row = max(st.seconds / rows_probe, 1e-6)
+    rows = int(max(rows_probe, min(h, budget_s / per_row)))
+    step = max(1, h // rows)
+    _, _, _, st = osc.render(cam, params, accel=ob.ACCEL_OCTREE, row_step=step, row_phase=step // 2, threads=threads)
+    rows_done = len(range(step // 2, h, step))
+    rays = st.closest_rays + st.shadow_rays
+    return {
+        "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": st.threads, "kind": "port",
+        "sample": f"{rows_done} of {h} image rows (every {step}th), {rays} rays in {st.seconds:.1f} s, octree search, OpenMP",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="crytek_gi128_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--tris", type=int, default=0)
+    ap.add_argument("--samples", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mipt import abi, device, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    device.init(local_rank)
+
+    kind_name, tris, tex, samples, gi, width, height, div = WORKLOADS[args.workload]
+    tris = args.tris or tris
+    samples = args.samples or samples
+    kind = {"crytek": abi.SCENE_CRYTEK, "sponza": abi.SCENE_SPONZA}[kind_name]
+    scene = host.HostScene.atrium(kind, tris, tex, 1)
+    cam, sun = host.camera_preset(kind, width, height, div)
+    dev = device.Scene(scene.desc)
+    info = dev.info()
+
+    shard = dict(shard_rank=rank, shard_count=world, tile_size=32)
+    if args.shard == "samples" and world > 1:
+        per = (samples + world - 1) // world
+        shard = dict(sample_begin=min(samples, rank * per), sample_end=min(samples, (rank + 1) * per))
+    params = host.default_params(sun_pos=sun, global_illumination=gi, num_samples=samples, use_textures=1, use_normals=0,
+                                 chunk_samples=args.chunk, **shard)
+    frame = device.Frame(dev, cam, params)
+    npx = frame.num_pixels
+    accum = torch.zeros(npx * 3, dtype=torch.float32, device="cuda")
+    out = torch.zeros(npx * 3, dtype=torch.float32, device="cuda")
+
+    def step():
+        st = frame.accumulate(accum.data_ptr())
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            frame.finalize(accum.data_ptr(), out.data_ptr())
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([
+        float(sum(s.closest_rays + s.shadow_rays for s in stats)),
+        float(sum(s.closest_triangle_tests for s in stats)), float(sum(s.closest_node_visits for s in stats)),
+        float(sum(s.closest_ms for s in stats)), float(sum(s.closest_launches for s in stats)),
+        float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
+        float(sum(s.shadow_ms for s in stats)), float(sum(s.closest_rays for s in stats)),
+    ], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # rays and counters add over ranks; kernel time is per-rank wall time of rank 0's kernels
+        sums = tot.clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        total_rays = sums[0].item()
+    else:
+        total_rays = tot[0].item()
+    elapsed = tmax.item()
+
+    if rank == 0:
+        s0 = stats[-1]
+        closest_s = tot[3].item() / 1e3                 # rank 0's closest-hit kernel time over the timed steps
+        flops = FLOP_PER_TRI_TEST * tot[1].item() + FLOP_PER_BOX_TEST * 2 * tot[2].item()
+        bytes_ = BYTES_PER_TRI_TEST * tot[1].item() + BYTES_PER_NODE * tot[2].item()
+        achieved_tf = flops / closest_s / 1e12 if closest_s > 0 else 0.0
+        launches = max(tot[4].item(), 1.0)
+        result = {
+            "metric": "Mrays/s (1 & 8 GPU) + render time, Crytek Sponza GI 128 spp 1080p",
+            "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": args.workload, "scene": scene.label, "triangles": int(info.num_triangles),
+                "materials": int(info.num_materials), "image": f"{cam.image_size[0]}x{cam.image_size[1]}",
+                "samples": samples, "global_illumination": bool(gi), "textures": True, "normal_maps": False,
+                "parallelism": f"{args.shard}x{world}", "rays_per_frame": total_rays / args.steps,
+                "render_time_s": elapsed / args.steps, "bvh_build_ms": info.build_ms, "bvh_depth": int(info.max_depth),
+                "bvh_sah_cost": info.sah_cost, "samples_per_pass": int(s0.chunk_samples),
+            },
+            "roofline": {
+                "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
+                "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
+                "triangle_tests_per_s": tot[1].item() / closest_s if closest_s > 0 else 0.0,
+                "node_visits_per_s": tot[2].item() / closest_s if closest_s > 0 else 0.0,
+                "closest_rays_per_s": tot[8].item() / closest_s if closest_s > 0 else 0.0,
+                "algorithmic_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
+                "hbm_frac": (bytes_ / closest_s / 1e9) / HBM_PEAK_GBS if closest_s > 0 else 0.0,
+                "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, cam, params)
+            result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / max(result["cpu_baseline"]["value"], 1e-9)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

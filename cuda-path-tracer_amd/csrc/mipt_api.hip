@@ -1,0 +1,577 @@
+// C ABI of libmipt.so (include/mipt.h): scene upload + BVH build, work buffers, the
+// wavefront render loop.  Replaces the host side of CCUDAPathTracer::CalcRays,
+// PathTracer.cu:556-771.
+#include "pt_internal.h"
+
+#include <chrono>
+#include <math.h>
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int g_device = -1;
+static int g_numCUs = 256;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MIPT_E_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct mipt_scene {
+    DevScene dev = {};
+    BvhResult bvh;
+    float4* attr = nullptr;
+    int32_t* triMat = nullptr;
+    DevMaterial* mats = nullptr;
+    uint32_t* texels = nullptr;
+    float* texelsF = nullptr;
+    int64_t numTris = 0;
+    int32_t numMats = 0;
+    int64_t geometryBytes = 0, textureBytes = 0;
+    double uploadMs = 0;
+    hipStream_t stream = nullptr;
+};
+
+struct mipt_frame {
+    mipt_scene* scene = nullptr;
+    mipt_camera cam = {};
+    mipt_params prm = {};
+    DevRender R = {};
+    int32_t W = 0, H = 0, P = 0;
+    int32_t chunk = 1;            // samples per pass
+    int64_t slotCap = 0;          // path slots per pass
+    hipStream_t stream = nullptr;
+    // per pixel
+    RayQueue primQ = {}; float4* primHit = nullptr; float4* pixState = nullptr; int32_t* triId = nullptr;
+    int32_t* actPix = nullptr; float4* pixAccum = nullptr; RayQueue primShadowQ = {};
+    // per path slot
+    RayQueue q[2] = {}; RayQueue shadowQ = {}; float4* hit = nullptr; float4* pathState = nullptr;
+    // counters
+    int32_t* counters = nullptr; int32_t numCounters = 0;
+    unsigned long long* stats = nullptr;
+    std::vector<hipEvent_t> events;
+    int32_t lastActive = 0;
+};
+
+extern "C" {
+
+const char* mipt_last_error(void) { return g_err.c_str(); }
+
+int mipt_init(int32_t device)
+{
+    int count = 0;
+    HIPTRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(MIPT_E_INVALID, "device %d out of range (%d devices)", device, count);
+    HIPTRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPTRY(hipGetDeviceProperties(&prop, device));
+    g_numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_device = device;
+    return MIPT_OK;
+}
+
+int mipt_device_name(char* buf, int32_t buflen)
+{
+    if (!buf || buflen <= 0) return fail(MIPT_E_INVALID, "null buffer");
+    if (g_device < 0) { int rc = mipt_init(0); if (rc) return rc; }
+    hipDeviceProp_t prop;
+    HIPTRY(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return MIPT_OK;
+}
+
+static int ensure_init()
+{
+    if (g_device < 0) return mipt_init(0);
+    HIPTRY(hipSetDevice(g_device));
+    return MIPT_OK;
+}
+
+void mipt_scene_destroy(mipt_scene* s)
+{
+    if (!s) return;
+    mipt_free_bvh(&s->bvh);
+    if (s->attr) (void)hipFree(s->attr);
+    if (s->triMat) (void)hipFree(s->triMat);
+    if (s->mats) (void)hipFree(s->mats);
+    if (s->texels) (void)hipFree(s->texels);
+    if (s->texelsF) (void)hipFree(s->texelsF);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+// true if every float of a texel array is an integer in 0..255 (then 4 bytes per texel lose nothing)
+static bool texels_are_bytes(const float* f, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        float v = f[i];
+        if (!(v >= 0.0f && v <= 255.0f) || v != (float)(int)v) return false;
+    }
+    return true;
+}
+
+int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt, mipt_scene** out)
+{
+    if (!desc || !out) return fail(MIPT_E_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->num_triangles < 0 || desc->num_meshes < 0 || desc->num_materials < 0)
+        return fail(MIPT_E_INVALID, "negative count in scene descriptor");
+    if ((desc->num_triangles > 0 && !desc->vertices) || (desc->num_meshes > 0 && !desc->meshes) ||
+        (desc->num_materials > 0 && !desc->materials))
+        return fail(MIPT_E_INVALID, "null array in scene descriptor");
+    int rc = ensure_init();
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+
+    // global triangle order: non-light meshes, in mesh order
+    int64_t n = 0;
+    for (int32_t i = 0; i < desc->num_meshes; i++) {
+        const mipt_mesh& m = desc->meshes[i];
+        if (m.num_triangles < 0 || m.first_triangle < 0 || m.first_triangle + m.num_triangles > desc->num_triangles)
+            return fail(MIPT_E_INVALID, "mesh %d addresses triangles outside the vertex array", i);
+        if (m.material >= desc->num_materials) return fail(MIPT_E_INVALID, "mesh %d names material %d of %d", i, m.material, desc->num_materials);
+        if (!m.is_light) n += m.num_triangles;
+    }
+    if (n >= (1ll << 30)) return fail(MIPT_E_LIMIT, "%lld triangles exceed the supported 2^30", (long long)n);
+
+    std::vector<mipt_vertex> attr; attr.reserve((size_t)n * 3);
+    std::vector<int32_t> triMat; triMat.reserve((size_t)n);
+    for (int32_t i = 0; i < desc->num_meshes; i++) {
+        const mipt_mesh& m = desc->meshes[i];
+        if (m.is_light) continue;
+        const mipt_vertex* v = desc->vertices + 3 * m.first_triangle;
+        attr.insert(attr.end(), v, v + 3 * m.num_triangles);
+        triMat.insert(triMat.end(), (size_t)m.num_triangles, m.material < 0 ? -1 : m.material);
+    }
+
+    // materials: byte-valued float texels are repacked to 4 bytes per texel (the reference
+    // uploads 12, PathTracer.cu:599-618); anything else stays float
+    std::vector<DevMaterial> mats((size_t)desc->num_materials);
+    std::vector<uint32_t> pool8; std::vector<float> poolF;
+    auto addTex = [&](const void* data, int32_t w, int32_t h, int32_t fmt, uint64_t& off, int32_t& dw, int32_t& dh, int32_t& dfmt) -> int {
+        off = 0; dw = dh = 0; dfmt = MIPT_TEXFMT_NONE;
+        if (!data || fmt == MIPT_TEX_NONE || w <= 0 || h <= 0) return MIPT_OK;
+        size_t cnt = (size_t)w * (size_t)h;
+        if (fmt == MIPT_TEX_BGRA8) {
+            off = pool8.size();
+            const uint32_t* p = (const uint32_t*)data;
+            pool8.insert(pool8.end(), p, p + cnt);
+            dfmt = MIPT_TEXFMT_U8;
+        } else if (fmt == MIPT_TEX_F32X3) {
+            const float* f = (const float*)data;
+            if (texels_are_bytes(f, cnt * 3)) {
+                off = pool8.size();
+                pool8.resize(pool8.size() + cnt);
+                uint32_t* dst = pool8.data() + off;
+                for (size_t i = 0; i < cnt; i++)
+                    dst[i] = (uint32_t)f[3 * i] | ((uint32_t)f[3 * i + 1] << 8) | ((uint32_t)f[3 * i + 2] << 16) | (255u << 24);
+                dfmt = MIPT_TEXFMT_U8;
+            } else {
+                off = poolF.size();
+                poolF.insert(poolF.end(), f, f + cnt * 3);
+                dfmt = MIPT_TEXFMT_F32;
+            }
+        } else {
+            return MIPT_E_INVALID;
+        }
+        dw = w; dh = h;
+        return MIPT_OK;
+    };
+    for (int32_t i = 0; i < desc->num_materials; i++) {
+        const mipt_material& m = desc->materials[i];
+        DevMaterial& d = mats[(size_t)i];
+        memset(&d, 0, sizeof(d));
+        if (addTex(m.tex_data, m.tex_width, m.tex_height, m.tex_format, d.texOffset, d.texW, d.texH, d.texFmt) ||
+            addTex(m.nml_data, m.nml_width, m.nml_height, m.nml_format, d.nmlOffset, d.nmlW, d.nmlH, d.nmlFmt))
+            return fail(MIPT_E_INVALID, "material %d has an unknown texel format", i);
+        d.diffuse[0] = m.diffuse[0]; d.diffuse[1] = m.diffuse[1]; d.diffuse[2] = m.diffuse[2];
+    }
+
+    mipt_scene* s = new mipt_scene();
+    s->numTris = n; s->numMats = desc->num_materials;
+#define SCTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mipt_scene_destroy(s); return fail(MIPT_E_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    SCTRY(hipStreamCreate(&s->stream));
+    if (n > 0) {
+        SCTRY(hipMalloc(&s->attr, sizeof(mipt_vertex) * 3 * (size_t)n));
+        SCTRY(hipMemcpy(s->attr, attr.data(), sizeof(mipt_vertex) * 3 * (size_t)n, hipMemcpyHostToDevice));
+        SCTRY(hipMalloc(&s->triMat, sizeof(int32_t) * (size_t)n));
+        SCTRY(hipMemcpy(s->triMat, triMat.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    if (!mats.empty()) {
+        SCTRY(hipMalloc(&s->mats, sizeof(DevMaterial) * mats.size()));
+        SCTRY(hipMemcpy(s->mats, mats.data(), sizeof(DevMaterial) * mats.size(), hipMemcpyHostToDevice));
+    }
+    if (!pool8.empty()) {
+        SCTRY(hipMalloc(&s->texels, 4 * pool8.size()));
+        SCTRY(hipMemcpy(s->texels, pool8.data(), 4 * pool8.size(), hipMemcpyHostToDevice));
+    }
+    if (!poolF.empty()) {
+        SCTRY(hipMalloc(&s->texelsF, 4 * poolF.size()));
+        SCTRY(hipMemcpy(s->texelsF, poolF.data(), 4 * poolF.size(), hipMemcpyHostToDevice));
+    }
+    s->textureBytes = (int64_t)(4 * pool8.size() + 4 * poolF.size());
+    s->uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);
+    if (rc) { mipt_scene_destroy(s); return fail(rc, "BVH build failed"); }
+    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 64 * (size_t)s->bvh.numNodeSlots + 48 * (size_t)s->bvh.numLeafSlots);
+
+    DevScene& D = s->dev;
+    D.nodes = s->bvh.nodes; D.triV0 = s->bvh.triV0; D.triE1 = s->bvh.triE1; D.triE2 = s->bvh.triE2;
+    D.attr = s->attr; D.triMat = s->triMat; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
+    D.rootCode = s->bvh.rootCode;
+    D.stackDepth = s->bvh.maxDepth + 2;
+    D.numTris = (int32_t)n; D.numMats = s->numMats;
+    if ((size_t)D.stackDepth * 64 * 4 > 160 * 1024) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too deep for the LDS stack"); }
+    *out = s;
+    return MIPT_OK;
+}
+
+int mipt_scene_get_info(const mipt_scene* s, mipt_scene_info* o)
+{
+    if (!s || !o) return fail(MIPT_E_INVALID, "null argument");
+    memset(o, 0, sizeof(*o));
+    o->num_triangles = s->numTris; o->num_nodes = s->bvh.numInner; o->num_leaves = s->bvh.numLeaves;
+    o->max_depth = s->bvh.maxDepth; o->num_materials = s->numMats;
+    o->geometry_bytes = s->geometryBytes; o->texture_bytes = s->textureBytes;
+    o->build_ms = s->bvh.buildMs; o->upload_ms = s->uploadMs; o->sah_cost = s->bvh.sahCost;
+    return MIPT_OK;
+}
+
+int mipt_scene_bvh_sizes(const mipt_scene* s, int64_t* nodeSlots, int64_t* leafSlots, uint32_t* rootCode)
+{
+    if (!s) return fail(MIPT_E_INVALID, "null scene");
+    if (nodeSlots) *nodeSlots = s->bvh.numNodeSlots;
+    if (leafSlots) *leafSlots = s->bvh.numLeafSlots;
+    if (rootCode) *rootCode = s->bvh.rootCode;
+    return MIPT_OK;
+}
+
+int mipt_scene_download_bvh(const mipt_scene* s, float* nodes, float* v0, float* e1, float* e2)
+{
+    if (!s) return fail(MIPT_E_INVALID, "null scene");
+    if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 64 * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
+    if (v0 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(v0, s->bvh.triV0, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
+    if (e1 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e1, s->bvh.triE1, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
+    if (e2 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e2, s->bvh.triE2, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
+    return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int mipt_trace_rays(mipt_scene* s, const float* rays, int64_t n, float eps, int32_t* outTri, float* outTuv, uint8_t* outAny)
+{
+    if (!s || (n > 0 && !rays)) return fail(MIPT_E_INVALID, "null argument");
+    if (n <= 0) return MIPT_OK;
+    if (n >= (1ll << 31) - 64) return fail(MIPT_E_LIMIT, "too many rays in one call");
+    int rc = ensure_init();
+    if (rc) return rc;
+    float* dRays = nullptr; RayQueue q = {}; float4* hit = nullptr; uint8_t* flags = nullptr; int32_t* ctr = nullptr;
+    unsigned long long* stats = nullptr;
+    hipError_t e = hipSuccess;
+    std::vector<float4> hHit;
+    auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    tryq(hipMalloc(&dRays, 24 * (size_t)n)); tryq(hipMalloc(&q.o, 16 * (size_t)n)); tryq(hipMalloc(&q.d, 16 * (size_t)n));
+    tryq(hipMalloc(&hit, 16 * (size_t)n)); tryq(hipMalloc(&flags, (size_t)n)); tryq(hipMalloc(&ctr, 16)); tryq(hipMalloc(&stats, 8 * ST_COUNT));
+    if (e == hipSuccess) {
+        int32_t hc[4] = { (int32_t)n, 0, 0, 0 };
+        tryq(hipMemcpy(dRays, rays, 24 * (size_t)n, hipMemcpyHostToDevice));
+        tryq(hipMemcpy(ctr, hc, 16, hipMemcpyHostToDevice));
+        tryq(hipMemset(stats, 0, 8 * ST_COUNT));
+        launch_pack_rays(dRays, n, q, s->stream);
+        if (outTri || outTuv) launch_closest(s->dev, q, ctr, (int32_t)n, ctr + 1, hit, eps, stats, g_numCUs, s->stream);
+        if (outAny) launch_anyhit_flags(s->dev, q, ctr, (int32_t)n, ctr + 2, flags, eps, stats, g_numCUs, s->stream);
+        tryq(hipStreamSynchronize(s->stream));
+        tryq(hipGetLastError());
+        if (e == hipSuccess && (outTri || outTuv)) {
+            hHit.resize((size_t)n);
+            tryq(hipMemcpy(hHit.data(), hit, 16 * (size_t)n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n && e == hipSuccess; i++) {
+                int32_t tri; memcpy(&tri, &hHit[(size_t)i].w, 4);
+                if (outTri) outTri[i] = tri;
+                if (outTuv) { outTuv[3 * i] = tri >= 0 ? hHit[(size_t)i].x : 0; outTuv[3 * i + 1] = tri >= 0 ? hHit[(size_t)i].y : 0; outTuv[3 * i + 2] = tri >= 0 ? hHit[(size_t)i].z : 0; }
+            }
+        }
+        if (e == hipSuccess && outAny) tryq(hipMemcpy(outAny, flags, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dRays); (void)hipFree(q.o); (void)hipFree(q.d); (void)hipFree(hit); (void)hipFree(flags); (void)hipFree(ctr); (void)hipFree(stats);
+    if (e != hipSuccess) return fail(MIPT_E_DEVICE, "mipt_trace_rays: %s", hipGetErrorString(e));
+    return MIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static int fill_render(mipt_frame* f, const mipt_camera* cam, const mipt_params* p)
+{
+    if (cam->div <= 0 || cam->client_width <= 0 || cam->client_height <= 0) return fail(MIPT_E_INVALID, "bad camera size");
+    int32_t W = cam->client_width / cam->div, H = cam->client_height / cam->div;   // PathTracer.cu:559-560
+    if (W <= 0 || H <= 0) return fail(MIPT_E_INVALID, "empty image");
+    if ((int64_t)W * H >= (1ll << 30)) return fail(MIPT_E_LIMIT, "image too large");
+    DevRender& R = f->R;
+    memcpy(R.toLocal, cam->to_local, sizeof(R.toLocal));
+    R.p0 = cam->p0; R.p1 = cam->p1; R.clientW = cam->client_width; R.clientH = cam->client_height; R.div = cam->div;
+    R.W = W; R.H = H;
+    R.sun[0] = p->sun_pos[0]; R.sun[1] = p->sun_pos[1]; R.sun[2] = p->sun_pos[2];
+    R.sunIntensity = p->sun_intensity;
+    R.gi = p->global_illumination != 0; R.useTextures = p->use_textures != 0; R.useNormals = p->use_normals != 0;
+    R.normalizeNormalMap = p->normalize_normal_map != 0;
+    R.eps = p->epsilon; R.seed = p->seed;
+    int32_t ns = p->num_samples;
+    if (ns < 1) ns = 1;
+    if (ns > 10000) ns = 10000;                                                       // RayTracerView.cpp:785-786
+    R.numSamples = ns;
+    R.shardCount = p->shard_count > 1 ? p->shard_count : 1;
+    R.shardRank = p->shard_rank;
+    if (R.shardRank < 0 || R.shardRank >= R.shardCount) return fail(MIPT_E_INVALID, "shard_rank %d outside 0..%d", p->shard_rank, R.shardCount - 1);
+    R.tileSize = p->tile_size > 0 ? p->tile_size : 32;
+    R.tilesX = (W + R.tileSize - 1) / R.tileSize;
+    if (p->sample_begin < 0 || p->sample_end < 0 || p->sample_end > ns || p->sample_begin > p->sample_end)
+        return fail(MIPT_E_INVALID, "sample range [%d,%d) outside [0,%d)", p->sample_begin, p->sample_end, ns);
+    f->cam = *cam; f->prm = *p; f->W = W; f->H = H; f->P = W * H;
+    return MIPT_OK;
+}
+
+void mipt_frame_destroy(mipt_frame* f)
+{
+    if (!f) return;
+    void* ptrs[] = { f->primQ.o, f->primQ.d, f->primHit, f->pixState, f->triId, f->actPix, f->pixAccum, f->primShadowQ.o, f->primShadowQ.d,
+                     f->q[0].o, f->q[0].d, f->q[1].o, f->q[1].d, f->shadowQ.o, f->shadowQ.d, f->hit, f->pathState, f->counters, f->stats };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : f->events) (void)hipEventDestroy(e);
+    delete f;
+}
+
+#define MAX_PASSES 10000
+// counters: [0] primary count, [1] primary head, [2] primary shadow count, [3] primary shadow head,
+// [4] active count, then per pass 12: for level 1..3: count, closest head, shadow count, shadow head
+#define CTR_FIXED 8
+#define CTR_PER_PASS 12
+
+int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* p, mipt_frame** out)
+{
+    if (!s || !cam || !p || !out) return fail(MIPT_E_INVALID, "null argument");
+    *out = nullptr;
+    int rc = ensure_init();
+    if (rc) return rc;
+    mipt_frame* f = new mipt_frame();
+    f->scene = s; f->stream = s->stream;
+    rc = fill_render(f, cam, p);
+    if (rc) { delete f; return rc; }
+    const int64_t P = f->P;
+    const int32_t ns = f->R.numSamples;
+    // samples per pass: about 16M path slots unless the caller fixes it
+    int32_t chunk = p->chunk_samples > 0 ? p->chunk_samples : (int32_t)((16ll << 20) / (P > 0 ? P : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > ns) chunk = ns;
+    if ((int64_t)chunk * P >= (1ll << 31) - 256) chunk = (int32_t)(((1ll << 31) - 256) / P);
+    if (chunk < 1) { delete f; return fail(MIPT_E_LIMIT, "image too large for one pass"); }
+    f->chunk = chunk;
+    f->slotCap = f->R.gi ? (int64_t)chunk * P : 0;
+#define FRTRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { mipt_frame_destroy(f); return fail(e_ == hipErrorOutOfMemory ? MIPT_E_NOMEM : MIPT_E_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+    FRTRY(hipMalloc(&f->primQ.o, 16 * (size_t)P)); FRTRY(hipMalloc(&f->primQ.d, 16 * (size_t)P));
+    FRTRY(hipMalloc(&f->primShadowQ.o, 16 * (size_t)P)); FRTRY(hipMalloc(&f->primShadowQ.d, 16 * (size_t)P));
+    FRTRY(hipMalloc(&f->primHit, 16 * (size_t)P));
+    FRTRY(hipMalloc(&f->pixState, 64 * (size_t)P));
+    FRTRY(hipMalloc(&f->triId, 4 * (size_t)P));
+    FRTRY(hipMalloc(&f->actPix, 4 * (size_t)P));
+    FRTRY(hipMalloc(&f->pixAccum, 16 * (size_t)P));
+    if (f->slotCap > 0) {
+        size_t sc = (size_t)f->slotCap;
+        for (int k = 0; k < 2; k++) { FRTRY(hipMalloc(&f->q[k].o, 16 * sc)); FRTRY(hipMalloc(&f->q[k].d, 16 * sc)); }
+        FRTRY(hipMalloc(&f->shadowQ.o, 16 * sc)); FRTRY(hipMalloc(&f->shadowQ.d, 16 * sc));
+        FRTRY(hipMalloc(&f->hit, 16 * sc));
+        FRTRY(hipMalloc(&f->pathState, 16 * 3 * sc));
+    }
+    int32_t passes = (ns + chunk - 1) / chunk;
+    f->numCounters = CTR_FIXED + CTR_PER_PASS * passes;
+    FRTRY(hipMalloc(&f->counters, 4 * (size_t)f->numCounters));
+    FRTRY(hipMalloc(&f->stats, 8 * ST_COUNT));
+    f->events.resize(2 + 2 * (size_t)(2 + passes * 6));
+    for (auto& e : f->events) { e = nullptr; FRTRY(hipEventCreate(&e)); }
+    *out = f;
+    return MIPT_OK;
+}
+
+int mipt_frame_set_params(mipt_frame* f, const mipt_camera* cam, const mipt_params* p)
+{
+    if (!f || !cam || !p) return fail(MIPT_E_INVALID, "null argument");
+    if (cam->client_width / (cam->div > 0 ? cam->div : 1) != f->W || cam->client_height / (cam->div > 0 ? cam->div : 1) != f->H)
+        return fail(MIPT_E_INVALID, "image size differs from the frame's");
+    int32_t ns = p->num_samples < 1 ? 1 : (p->num_samples > 10000 ? 10000 : p->num_samples);
+    int32_t passes = (ns + f->chunk - 1) / f->chunk;
+    if (CTR_FIXED + CTR_PER_PASS * passes > f->numCounters) return fail(MIPT_E_INVALID, "more samples than the frame was created for");
+    if ((p->global_illumination != 0) && f->slotCap == 0) return fail(MIPT_E_INVALID, "frame was created without global illumination");
+    return fill_render(f, cam, p);
+}
+
+int64_t mipt_frame_num_pixels(const mipt_frame* f) { return f ? f->P : 0; }
+
+int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt_progress_fn progress, void* user)
+{
+    if (!f || !d_accum) return fail(MIPT_E_INVALID, "null argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    mipt_scene* sc = f->scene;
+    hipStream_t st = f->stream;
+    const DevRender& R = f->R;
+    const DevScene& S = sc->dev;
+    const int32_t P = f->P;
+    const int64_t total = P;
+    size_t ev = 0;
+    std::vector<std::pair<size_t, int>> spans;    // (first event index, kind 0 closest / 1 shadow)
+    auto spanBegin = [&](int kind) { spans.push_back({ ev, kind }); (void)hipEventRecord(f->events[ev++], st); };
+    auto spanEnd = [&]() { (void)hipEventRecord(f->events[ev++], st); };
+
+    if (progress) progress(0, total, user);                                             // PathTracer.cu:721
+    HIPTRY(hipEventRecord(f->events[ev++], st));                                   // events[0] = start of the call
+    size_t evEndIdx = ev++;                                                        // events[1] = end of the call
+    HIPTRY(hipMemsetAsync(f->counters, 0, 4 * (size_t)f->numCounters, st));
+    HIPTRY(hipMemsetAsync(f->stats, 0, 8 * ST_COUNT, st));
+    HIPTRY(hipMemsetAsync(d_accum, 0, 12 * (size_t)P, st));
+    launch_set_i32(f->counters + 0, P, st);
+
+    // depth 0: primary rays, their surfaces and shadow rays
+    launch_raygen(R, f->primQ, st);
+    spanBegin(0);
+    launch_closest(S, f->primQ, f->counters + 0, P, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st);
+    spanEnd();
+    launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, st);
+    spanBegin(1);
+    launch_shadow(S, f->primShadowQ, f->counters + 2, P, f->counters + 3, f->pixState, f->pathState, f->slotCap, R.eps, f->stats, g_numCUs, st);
+    spanEnd();
+
+    int32_t nAct = 0;
+    int32_t usedChunk = 0;
+    if (R.gi) {
+        HIPTRY(hipMemcpyAsync(&nAct, f->counters + 4, 4, hipMemcpyDeviceToHost, st));
+        HIPTRY(hipStreamSynchronize(st));
+        f->lastActive = nAct;
+        int32_t sb = f->prm.sample_begin, se = f->prm.sample_end;
+        if (sb == 0 && se == 0) se = R.numSamples;
+        if (nAct > 0 && se > sb) {
+            HIPTRY(hipMemsetAsync(f->pixAccum, 0, 16 * (size_t)nAct, st));
+            // the pass size was fixed for the whole image; with fewer active pixels more samples fit
+            int64_t fit = f->slotCap / nAct;
+            int32_t chunk = (f->prm.chunk_samples > 0) ? f->chunk : (int32_t)(fit > (se - sb) ? (se - sb) : fit);
+            if (chunk < 1) chunk = 1;
+            int32_t maxPasses = (f->numCounters - CTR_FIXED) / CTR_PER_PASS;
+            if ((se - sb + chunk - 1) / chunk > maxPasses) chunk = (se - sb + maxPasses - 1) / maxPasses;
+            usedChunk = chunk;
+            int pass = 0;
+            for (int32_t n0 = sb; n0 < se; n0 += chunk, pass++) {
+                int32_t Sn = (se - n0 < chunk) ? se - n0 : chunk;
+                int64_t slots = (int64_t)nAct * Sn;
+                int32_t* C = f->counters + CTR_FIXED + CTR_PER_PASS * pass;
+                launch_set_i32(C + 0, (int32_t)slots, st);
+                HIPTRY(hipMemsetAsync(f->pathState, 0, 16 * 3 * (size_t)slots, st));
+                launch_gen_first_bounce(R, f->pixState, f->actPix, nAct, n0, Sn, f->q[0], st);
+                for (int level = 1; level <= 3; level++) {
+                    int32_t* Lc = C + 4 * (level - 1);       // count, closest head, shadow count, shadow head
+                    int32_t* nextCount = (level < 3) ? C + 4 * level : nullptr;
+                    RayQueue cur = f->q[(level - 1) & 1], nxt = f->q[level & 1];
+                    spanBegin(0);
+                    launch_closest(S, cur, Lc + 0, (int32_t)slots, Lc + 1, f->hit, R.eps, f->stats, g_numCUs, st);
+                    spanEnd();
+                    launch_shade_bounce(S, R, cur, f->hit, Lc + 0, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
+                                        f->shadowQ, Lc + 2, nxt, nextCount, st);
+                    spanBegin(1);
+                    launch_shadow(S, f->shadowQ, Lc + 2, (int32_t)slots, Lc + 3, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
+                    spanEnd();
+                }
+                launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);
+                if (progress) {
+                    HIPTRY(hipStreamSynchronize(st));
+                    progress(total * (n0 + Sn - sb) / (se - sb), total, user);
+                }
+            }
+            launch_scatter_accum(f->pixAccum, f->actPix, nAct, d_accum, st);
+        }
+    }
+    HIPTRY(hipEventRecord(f->events[evEndIdx], st));
+    HIPTRY(hipStreamSynchronize(st));
+    HIPTRY(hipGetLastError());
+    if (progress && !(R.gi && nAct > 0)) progress(total, total, user);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        unsigned long long h[ST_COUNT];
+        HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
+        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS];
+        stats->node_visits = h[ST_CLOSEST_NODES] + h[ST_SHADOW_NODES];
+        stats->triangle_tests = h[ST_CLOSEST_TRIS] + h[ST_SHADOW_TRIS];
+        stats->closest_node_visits = h[ST_CLOSEST_NODES]; stats->closest_triangle_tests = h[ST_CLOSEST_TRIS];
+        stats->active_pixels = (uint64_t)nAct;
+        for (auto& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, f->events[sp.first], f->events[sp.first + 1]) == hipSuccess) {
+                if (sp.second == 0) { stats->closest_ms += ms; stats->closest_launches++; }
+                else { stats->shadow_ms += ms; stats->shadow_launches++; }
+            }
+        }
+        float tot = 0;
+        if (hipEventElapsedTime(&tot, f->events[0], f->events[evEndIdx]) == hipSuccess) stats->total_ms = tot;
+        stats->shade_ms = stats->total_ms - stats->closest_ms - stats->shadow_ms;
+        stats->chunk_samples = usedChunk;
+    }
+    return MIPT_OK;
+}
+
+int mipt_frame_finalize(mipt_frame* f, const float* d_accum, float* d_out)
+{
+    if (!f || !d_accum || !d_out) return fail(MIPT_E_INVALID, "null argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    launch_finalize(f->R, f->pixState, d_accum, d_out, f->stream);
+    HIPTRY(hipStreamSynchronize(f->stream));
+    HIPTRY(hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_frame_primary_ids(mipt_frame* f, int32_t* out)
+{
+    if (!f || !out) return fail(MIPT_E_INVALID, "null argument");
+    HIPTRY(hipMemcpy(out, f->triId, 4 * (size_t)f->P, hipMemcpyDeviceToHost));
+    return MIPT_OK;
+}
+
+int mipt_render(mipt_scene* s, const mipt_camera* cam, const mipt_params* p, float* out, int32_t* outTri, mipt_stats* stats,
+                mipt_progress_fn progress, void* user)
+{
+    if (!out) return fail(MIPT_E_INVALID, "null output image");
+    mipt_frame* f = nullptr;
+    int rc = mipt_frame_create(s, cam, p, &f);
+    if (rc) return rc;
+    float *dAccum = nullptr, *dOut = nullptr;
+    size_t bytes = 12 * (size_t)f->P;
+    hipError_t e = hipMalloc(&dAccum, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dOut, bytes);
+    if (e != hipSuccess) { (void)hipFree(dAccum); mipt_frame_destroy(f); return fail(MIPT_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    rc = mipt_frame_accumulate(f, dAccum, stats, progress, user);
+    if (!rc) rc = mipt_frame_finalize(f, dAccum, dOut);
+    if (!rc && hipMemcpy(out, dOut, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIPT_E_DEVICE, "copy of the image failed");
+    if (!rc && outTri) rc = mipt_frame_primary_ids(f, outTri);
+    (void)hipFree(dAccum); (void)hipFree(dOut);
+    mipt_frame_destroy(f);
+    return rc;
+}
+
+int mipt_device_alloc(void** out, int64_t bytes)
+{
+    if (!out || bytes <= 0) return fail(MIPT_E_INVALID, "bad allocation request");
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPTRY(hipMalloc(out, (size_t)bytes));
+    return MIPT_OK;
+}
+int mipt_device_free(void* p) { if (p) HIPTRY(hipFree(p)); return MIPT_OK; }
+int mipt_copy_to_host(void* dst, const void* src, int64_t bytes) { HIPTRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return MIPT_OK; }
+int mipt_copy_to_device(void* dst, const void* src, int64_t bytes) { HIPTRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); return MIPT_OK; }
+int mipt_device_synchronize(void) { HIPTRY(hipDeviceSynchronize()); return MIPT_OK; }
+
+} // extern "C"

@@ -1,0 +1,238 @@
+// Device-side arithmetic of the path tracer: float3 helpers, the ray/triangle test, the
+// BVH box test, sampling, the counter-based random stream and wave64 queue primitives.
+//
+// Everything that decides a result (which triangle is hit, at what t, with what radiance)
+// is plain IEEE fp32 with one rounding per operation, in the operand order of the
+// reference's CPU path, so that results can be compared bit for bit with a CPU
+// restatement.  The translation unit is compiled with -ffp-contract=off; the only fused
+// operations are the explicit __builtin_fmaf calls of the box test, which is conservative
+// by construction (boxes are padded) and never decides a result.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "pt_internal.h"
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 f3sub(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 f3add(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 f3scale(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+// XMVector3Dot: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float f3dot(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// XMVector3Cross
+__device__ __forceinline__ F3 f3cross(F3 a, F3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// XMVector3Normalize: v / sqrt(dot(v,v)), 0 for a zero vector, NaN for an infinite one
+__device__ __forceinline__ F3 f3normalize(F3 v)
+{
+    float lsq = f3dot(v, v);
+    float len = sqrtf(lsq);
+    if (len == 0.0f) return f3(0.0f, 0.0f, 0.0f);
+    if (lsq == INFINITY) return f3(NAN, NAN, NAN);
+    return f3(v.x / len, v.y / len, v.z / len);
+}
+
+// ---------------------------------------------------------------------------------------
+// Random stream of the harness: uniform in [0,1) keyed by (seed, pixel, sample, depth, dim).
+// Replaces cuRAND XORWOW of PathTracer.cu:516-518,436-437 and mt19937 of
+// CPUPathTracer.cpp:345-346,418-419.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float rng_u01(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t dim)
+{
+    uint32_t h = mix32(seed + 0x9e3779b9U);
+    h = mix32(h ^ pixel);
+    h = mix32(h ^ sample);
+    h = mix32(h ^ (depth * 2U + dim + 0x632be5abU));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+#define PT_PI 3.14159265f      /* M_PI of PathTracer.cu:15 / CPUPathTracer.cpp:12 */
+#define PT_BIAS 0.01f          /* PathTracer.cu:400 */
+
+// uniformSampleHemisphere, CPUPathTracer.cpp:448-456 / PathTracer.cu:362-371
+__device__ __forceinline__ F3 sample_hemisphere(float r1, float r2)
+{
+    float sinTheta = sqrtf(1 - r1 * r1);
+    float phi = 2 * PT_PI * r2;
+    float x = sinTheta * cosf(phi);
+    float z = sinTheta * sinf(phi);
+    return f3(x, r1, z);
+}
+
+// CreateCoordinateSystem, CPUPathTracer.cpp:458-472: the divisor is hypot() evaluated in
+// double and rounded to float
+__device__ __forceinline__ void coordinate_system(F3 N, F3& Nt, F3& Nb)
+{
+    if (fabsf(N.x) > fabsf(N.y)) {
+        float h = (float)sqrt((double)N.x * (double)N.x + (double)N.z * (double)N.z);
+        Nt = f3(N.z / h, 0.0f / h, -N.x / h);
+    } else {
+        float h = (float)sqrt((double)N.y * (double)N.y + (double)N.z * (double)N.z);
+        Nt = f3(0.0f / h, -N.z / h, N.y / h);
+    }
+    Nb = f3cross(N, Nt);
+}
+
+// world = x*Nb + y*N + z*Nt, CPUPathTracer.cpp:421-425
+__device__ __forceinline__ F3 to_world(F3 s, F3 N, F3 Nt, F3 Nb)
+{
+    return f3(s.x * Nb.x + s.y * N.x + s.z * Nt.x,
+              s.x * Nb.y + s.y * N.y + s.z * Nt.y,
+              s.x * Nb.z + s.y * N.z + s.z * Nt.z);
+}
+
+// ---------------------------------------------------------------------------------------
+// XNA::IntersectRayTriangle, xnacollision.cpp:1068-1168 (epsilon as a parameter; 1e-5
+// gives IntersectRayTriangle of PathTracer.cu:149-191).  e1 = v1 - v0 and e2 = v2 - v0 are
+// the same fp32 differences the reference forms per test, taken once at build time.
+// Returns true on acceptance with t, u, v divided by det.
+__device__ __forceinline__ bool ray_triangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, float eps, float& t, float& u, float& v)
+{
+    F3 p = f3cross(d, e2);
+    float det = f3dot(e1, p);
+    F3 s = f3sub(o, v0);
+    float uu = f3dot(s, p);
+    F3 q = f3cross(s, e1);
+    float vv = f3dot(d, q);
+    float tt = f3dot(e2, q);
+    bool pos = det >= eps;
+    bool neg = det <= -eps;
+    // the reference collects "no intersection" conditions, so a NaN comparison does not reject
+    bool rejP = (uu < 0.0f) | (uu > det) | (vv < 0.0f) | ((uu + vv) > det) | (tt < 0.0f);
+    bool rejN = (uu > 0.0f) | (uu < det) | (vv > 0.0f) | ((uu + vv) < det) | (tt > 0.0f);
+    bool accept = pos ? !rejP : (neg & !rejN);
+    if (accept) {
+        float inv = 1.0f / det;
+        t = tt * inv; u = uu * inv; v = vv * inv;
+    }
+    return accept;
+}
+
+// ---------------------------------------------------------------------------------------
+// Ray prepared for the box test: reciprocal direction and -origin/direction, so that a slab
+// distance is one fused multiply-add.  A zero direction component is replaced by 1e-30.
+struct BoxRay { float ix, iy, iz, nx, ny, nz; };
+
+__device__ __forceinline__ BoxRay make_box_ray(F3 o, F3 d)
+{
+    BoxRay r;
+    float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.nx = -o.x * r.ix; r.ny = -o.y * r.iy; r.nz = -o.z * r.iz;
+    return r;
+}
+
+// entry distance of the ray into the box, or a value > exit distance on a miss
+__device__ __forceinline__ bool box_test(const BoxRay& r, float bminx, float bminy, float bminz, float bmaxx,
+                                         float bmaxy, float bmaxz, float tcull, float& tnear)
+{
+    float x0 = __builtin_fmaf(bminx, r.ix, r.nx), x1 = __builtin_fmaf(bmaxx, r.ix, r.nx);
+    float y0 = __builtin_fmaf(bminy, r.iy, r.ny), y1 = __builtin_fmaf(bmaxy, r.iy, r.ny);
+    float z0 = __builtin_fmaf(bminz, r.iz, r.nz), z1 = __builtin_fmaf(bmaxz, r.iz, r.nz);
+    float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
+    tnear = tmin;
+    return tmin <= tmax;
+}
+
+struct Hit { float t, u, v; int32_t tri; };
+
+// Closest-hit (ANY = false) or any-hit (ANY = true) search.  stack points at this lane's
+// column of the wave's LDS stack; entry k lives at stack[k * 64].
+// Closest: the accepted triangle with the smallest t below FLT_MAX; equal t -> lowest
+// global triangle id (TraceRays, PathTracer.cu:244-288 / Trace, CPUPathTracer.cpp:251-285).
+// Any: true as soon as one triangle is accepted with t < FLT_MAX (the bHitOnly result).
+template <bool ANY>
+__device__ __forceinline__ bool traverse(const DevScene& S, F3 o, F3 d, float eps, uint32_t* stack,
+                                         Hit& hit, uint32_t& nodeCount, uint32_t& triCount)
+{
+    hit.t = FLT_MAX; hit.u = 0; hit.v = 0; hit.tri = -1;
+    uint32_t cur = S.rootCode;
+    if (cur == MIPT_NO_NODE) return false;
+    BoxRay br = make_box_ray(o, d);
+    float tcull = FLT_MAX;
+    int sp = 0;
+    const float4* __restrict__ nodes = S.nodes;
+    for (;;) {
+        while (!(cur & MIPT_LEAF_BIT)) {
+            const float4* n = nodes + (size_t)cur * 4;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            nodeCount++;
+            float t0, t1;
+            bool h0 = box_test(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tcull, t0);
+            bool h1 = box_test(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tcull, t1);
+            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (h0 & h1) {
+                bool firstIs0 = t0 <= t1;
+                uint32_t nearC = firstIs0 ? c0 : c1, farC = firstIs0 ? c1 : c0;
+                stack[sp * 64] = farC;
+                sp = (sp + 1 < S.stackDepth) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
+                cur = nearC;
+            } else if (h0 | h1) {
+                cur = h0 ? c0 : c1;
+            } else {
+                if (sp == 0) return hit.tri >= 0;
+                sp--; cur = stack[sp * 64];
+            }
+        }
+        // leaf
+        uint32_t slot = cur & ~MIPT_LEAF_BIT;
+        uint32_t last;
+        do {
+            float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
+            triCount++;
+            float t, u, v;
+            if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
+                int32_t id = (int32_t)__float_as_uint(a.w);
+                if (ANY) {
+                    if (t < FLT_MAX) { hit.t = t; hit.tri = id; return true; }
+                } else if (t < hit.t || (t == hit.t && id < hit.tri)) {
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = id;
+                    tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+                }
+            }
+            last = __float_as_uint(b.w);
+            slot++;
+        } while (!last && slot < (uint32_t)S.numTris);
+        if (sp == 0) return hit.tri >= 0;
+        sp--; cur = stack[sp * 64];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// wave64 primitives
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Appends one entry per lane with pred set to a queue whose tail is *counter: one ballot,
+// one prefix popcount and a single atomic per wave.  Must be called by all lanes of the
+// wave that are still running.  Returns the entry index (valid where pred is set).
+__device__ __forceinline__ int wave_append(bool pred, int32_t* counter)
+{
+    unsigned long long mask = __ballot(pred);
+    int total = __popcll(mask);
+    int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    int base = 0;
+    if (total) {
+        int leader = __ffsll((long long)mask) - 1;
+        if (lane_id() == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader, 64);
+    }
+    return base + prefix;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v)
+{
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s;
+}

@@ -1,0 +1,131 @@
+// Internal declarations shared by the HIP translation units of libmipt.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mipt.h"
+
+// ---- device-side scene --------------------------------------------------------------
+//
+// BVH node slot (64 B = 4 x float4, fetched by one lane with four 16-byte loads from one
+// 64-byte-aligned record): the boxes of BOTH children live in the parent, so that one
+// fetch decides both descents.
+//   q0 = (c0min.x, c0min.y, c0min.z, c0max.x)
+//   q1 = (c0max.y, c0max.z, c1min.x, c1min.y)
+//   q2 = (c1min.z, c1max.x, c1max.y, c1max.z)
+//   q3 = (bits child0, bits child1, 0, 0)
+// A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  Leaf slots are three
+// parallel float4 arrays in BVH order (the three loads of a lane hit three arrays, consecutive
+// slots of one leaf are consecutive in each):
+//   triV0[s] = (v0.xyz, bits global triangle id)
+//   triE1[s] = (v1 - v0, bits 1 if last triangle of its leaf else 0)
+//   triE2[s] = (v2 - v0, 0)
+#define MIPT_LEAF_BIT 0x80000000u
+#define MIPT_NO_NODE  0xFFFFFFFFu
+
+#define MIPT_TEXFMT_NONE 0
+#define MIPT_TEXFMT_U8   1   // uint32 BGRA8 texels in DevScene::texels
+#define MIPT_TEXFMT_F32  2   // 3 floats per texel in DevScene::texelsF
+
+struct DevMaterial {
+    uint64_t texOffset;      // first texel (U8: uint32 index, F32: float index)
+    uint64_t nmlOffset;
+    int32_t  texW, texH, texFmt;
+    int32_t  nmlW, nmlH, nmlFmt;
+    float    diffuse[3];
+    int32_t  pad;
+};
+
+struct DevScene {
+    const float4*      nodes;
+    const float4*      triV0;
+    const float4*      triE1;
+    const float4*      triE2;
+    const float4*      attr;       // 6 float4 per global triangle: three (pos3, normal3, uv2) corners
+    const int32_t*     triMat;     // material per global triangle, -1 = none
+    const DevMaterial* mats;
+    const uint32_t*    texels;
+    const float*       texelsF;
+    uint32_t           rootCode;   // MIPT_NO_NODE for an empty scene
+    int32_t            stackDepth; // entries of the per-lane traversal stack
+    int32_t            numTris;
+    int32_t            numMats;
+};
+
+// render constants handed to the shading kernels by value
+struct DevRender {
+    float    toLocal[16];
+    float    p0, p1;
+    int32_t  clientW, clientH, div, W, H;
+    float    sun[3];
+    float    sunIntensity;
+    int32_t  gi, useTextures, useNormals, normalizeNormalMap;
+    float    eps;
+    uint32_t seed;
+    int32_t  numSamples;
+    int32_t  shardRank, shardCount, tileSize, tilesX;
+};
+
+// ---- statistics slots (uint64 each) ---------------------------------------------------
+enum {
+    ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
+    ST_COUNT = 8
+};
+
+// ---- BVH build result -------------------------------------------------------------------
+struct BvhResult {
+    float4*  nodes = nullptr;     // numNodeSlots * 4
+    float4*  triV0 = nullptr;
+    float4*  triE1 = nullptr;
+    float4*  triE2 = nullptr;
+    int64_t  numNodeSlots = 0;
+    int64_t  numLeafSlots = 0;
+    int64_t  numInner = 0;
+    int64_t  numLeaves = 0;
+    int32_t  maxDepth = 0;
+    uint32_t rootCode = MIPT_NO_NODE;
+    double   buildMs = 0;
+    double   sahCost = 0;
+};
+
+// Builds the BVH over numTris triangles whose corners are in d_attr (6 float4 per triangle).
+// Returns MIPT_OK or an error code; on error nothing is left allocated.
+int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_options* opt, hipStream_t stream,
+                   BvhResult* out);
+void mipt_free_bvh(BvhResult* r);
+
+// ---- kernel launchers (pt_kernels.hip) --------------------------------------------------
+struct RayQueue {
+    float4* o;        // origin.xyz, bits slot
+    float4* d;        // direction.xyz, bits level (shadow rays) / 0
+};
+
+void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s);
+// closest-hit over q[0 .. *d_count): hit[i] = (t, ua, va, bits triangle id or -1)
+void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s);
+// any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
+void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                   float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
+                   unsigned long long* d_stats, int numCUs, hipStream_t s);
+// any-hit for caller-supplied rays: out[i] = 1 if occluded
+void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                         uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s);
+// shading of the primary hits (level 0)
+void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* hit, float4* pixState,
+                          int32_t* triIdImage, RayQueue shadowQ, int32_t* d_shadowCount, int32_t* actPix,
+                          int32_t* d_actCount, hipStream_t s);
+// first-bounce rays of samples [n0, n0+S) of every active pixel
+void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const int32_t* actPix, int32_t nAct,
+                             int32_t n0, int32_t S, RayQueue q, hipStream_t s);
+// shading of bounce `level` (1..3): path state, shadow ray, next ray
+void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
+                         const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
+                         int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
+                         int32_t* d_shadowCount, RayQueue nextQ, int32_t* d_nextCount, hipStream_t s);
+// backward resolve of one pass and accumulation into the per-active-pixel sums
+void launch_resolve(const DevRender& R, const float4* pathState, int64_t slotsPerLevel, const int32_t* actPix,
+                    int32_t nAct, int32_t n0, int32_t S, float4* pixAccum, hipStream_t s);
+void launch_scatter_accum(const float4* pixAccum, const int32_t* actPix, int32_t nAct, float* d_accum, hipStream_t s);
+void launch_finalize(const DevRender& R, const float4* pixState, const float* d_accum, float* d_out, hipStream_t s);
+void launch_set_i32(int32_t* d_ptr, int32_t value, hipStream_t s);
+void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s);

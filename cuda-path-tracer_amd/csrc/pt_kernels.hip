@@ -1,0 +1,477 @@
+// Wavefront kernels of the path tracer.
+//
+// The reference evaluates one recursive Radiance() per pixel inside a single kernel
+// (PTKernel, PathTracer.cu:501-554).  Here the same estimator is cut into passes over
+// queues of rays:
+//   k_raygen          primary rays                           PathTracer.cu:512-539
+//   k_closest         closest-hit search                     TraceRays, PathTracer.cu:244-288
+//   k_shade_primary   surface + light at the first hit       Radiance, PathTracer.cu:389-428
+//   k_gen_first       the N hemisphere samples of a pixel    PathTracer.cu:435-445
+//   k_shade_bounce    surface + light + next sample          Radiance at depth 1..3
+//   k_shadow          any-hit towards the light              TraceRays(bHitOnly), :421
+//   k_resolve         per-level clamp, backwards             PathTracer.cu:449-462
+//   k_finalize        first-level sum, clamp, *255           PathTracer.cu:453-462, 550-552
+// A path slot is (first-bounce sample s of this pass, active pixel a): slot = s * nAct + a.
+#include "pt_device.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// k_raygen: CPUPathTracer.cpp:489-497 (the CPU flavour transforms (vx,vy,1) first and
+// normalises once; XMVector3TransformCoord/Normal evaluate ((z*r2 [+ r3]) + y*r1) + x*r0)
+__global__ void __launch_bounds__(256) k_raygen(DevRender R, RayQueue q)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= R.W * R.H) return;
+    int j = p % R.W, h = p / R.W;
+    const float* m = R.toLocal;
+    float vx = (+2.0f * (float)R.div * j / (float)R.clientW - 1.0f) / R.p0;
+    float vy = (-2.0f * (float)R.div * h / (float)R.clientH + 1.0f) / R.p1;
+    float r0 = ((0.0f * m[8] + m[12]) + 0.0f * m[4]) + 0.0f * m[0];
+    float r1 = ((0.0f * m[9] + m[13]) + 0.0f * m[5]) + 0.0f * m[1];
+    float r2 = ((0.0f * m[10] + m[14]) + 0.0f * m[6]) + 0.0f * m[2];
+    float r3 = ((0.0f * m[11] + m[15]) + 0.0f * m[7]) + 0.0f * m[3];
+    F3 dir;
+    dir.x = (1.0f * m[8] + vy * m[4]) + vx * m[0];
+    dir.y = (1.0f * m[9] + vy * m[5]) + vx * m[1];
+    dir.z = (1.0f * m[10] + vy * m[6]) + vx * m[2];
+    dir = f3normalize(dir);
+    q.o[p] = make_float4(r0 / r3, r1 / r3, r2 / r3, __int_as_float(p));
+    q.d[p] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+}
+
+void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s)
+{
+    int n = R.W * R.H;
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, s, R, q);
+}
+
+__global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
+void launch_set_i32(int32_t* d_ptr, int32_t value, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, s, d_ptr, value);
+}
+
+__global__ void __launch_bounds__(256) k_pack_rays(const float* rays, int64_t n, RayQueue q)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    q.o[i] = make_float4(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2], __int_as_float((int)i));
+    q.d[i] = make_float4(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5], 0.0f);
+}
+void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rays6, n, q);
+}
+
+// ---------------------------------------------------------------------------------------
+// Traversal kernels.  One wave per workgroup; a wave draws 64 rays at a time from the queue
+// through one atomic on *head and leaves when the queue is drained, so the grid can be
+// sized to the machine and needs no host-side knowledge of the queue length.
+// MODE 0: closest hit -> hit[i]; MODE 1: any-hit, clears the direct term of the ray's slot
+// when occluded; MODE 2: any-hit -> flags[i].
+template <int MODE>
+__global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
+                                               int32_t* head, float4* __restrict__ hit, float4* pixState0,
+                                               float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
+                                               float eps, unsigned long long* stats)
+{
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x;
+    uint32_t* stack = smem + lane;
+    const int n = *d_count;
+    uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(head, WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        int i = base + lane;
+        if (i < n) {
+            float4 o4 = q.o[i], d4 = q.d[i];
+            Hit h;
+            rayCount++;
+            bool found = traverse<MODE != 0>(S, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z), eps, stack, h, nodeCount, triCount);
+            if (MODE == 0) {
+                hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(found ? h.tri : -1));
+            } else if (MODE == 1) {
+                if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
+                    int slot = __float_as_int(o4.w), level = __float_as_int(d4.w);
+                    if (level == 0) pixState0[(size_t)slot * 4].x = 0.0f;
+                    else pathState[(size_t)(level - 1) * slotsPerLevel + slot].x = 0.0f;
+                }
+            } else {
+                flags[i] = found ? 1 : 0;
+            }
+        }
+    }
+    unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
+    if (lane == 0 && rs) {
+        atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_RAYS : ST_SHADOW_RAYS], rs);
+        atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_NODES : ST_SHADOW_NODES], ns);
+        atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_TRIS : ST_SHADOW_TRIS], ts);
+    }
+}
+
+static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
+{
+    // waves that can be resident: limited by LDS (160 KiB per CU) and by 32 waves per CU
+    int perCU = smemBytes ? (int)((160 * 1024) / smemBytes) : 32;
+    if (perCU > 32) perCU = 32;
+    if (perCU < 1) perCU = 1;
+    long long resident = (long long)numCUs * perCU;
+    long long needed = ((long long)maxCount + WAVE - 1) / WAVE;
+    long long g = needed < resident ? needed : resident;
+    return (int)(g < 1 ? 1 : g);
+}
+
+void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
+{
+    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats);
+}
+void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                   float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
+                   unsigned long long* d_stats, int numCUs, hipStream_t s)
+{
+    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats);
+}
+void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+                         uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
+{
+    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats);
+}
+
+// ---------------------------------------------------------------------------------------
+// Surface at a hit: attributes of CMesh::Intersect (CPUPathTracer.cpp:229-245), texture and
+// normal-map lookup of Trace (:286-341), shading frame and normal map of Radiance (:389-400).
+struct Surface {
+    F3 hp, N, Nt, Nb, albedo;
+};
+
+__device__ __forceinline__ float wrap01(float x)
+{
+    // the +-1 loops of CPUPathTracer.cpp:292-295; values they cannot bring into range are set to 0
+    if (!(fabsf(x) < 16777216.0f)) x = 0;
+    while (x > 1) { x = x - 1; }
+    while (x < 0) { x = x + 1; }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t fetch_texel_bgr(const DevScene& S, int fmt, uint64_t off, long idx)
+{
+    if (fmt == MIPT_TEXFMT_U8) return S.texels[off + (uint64_t)idx];
+    const float* f = S.texelsF + off + (uint64_t)idx * 3;
+    return ((uint32_t)f[0] & 255u) | (((uint32_t)f[1] & 255u) << 8) | (((uint32_t)f[2] & 255u) << 16);
+}
+
+__device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender& R, int tri, float ua, float va)
+{
+    Surface sf;
+    const float4* a = S.attr + (size_t)tri * 6;
+    float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+    // corner k: pos = (a[2k].x, a[2k].y, a[2k].z), normal = (a[2k].w, a[2k+1].x, a[2k+1].y), tex = (a[2k+1].z, a[2k+1].w)
+    float w = 1 - ua - va;
+    float u = w * a1.w + ua * a3.w + va * a5.w;          // :231 uses tex.y
+    float v = w * a1.z + ua * a3.z + va * a5.z;          // :232 uses tex.x
+    sf.hp.x = w * a0.x + ua * a2.x + va * a4.x;
+    sf.hp.y = w * a0.y + ua * a2.y + va * a4.y;
+    sf.hp.z = w * a0.z + ua * a2.z + va * a4.z;
+    F3 n;
+    n.x = (a0.w + a2.w + a4.w) / 3;
+    n.y = (a1.x + a3.x + a5.x) / 3;
+    n.z = (a1.y + a3.y + a5.y) / 3;
+    sf.N = f3normalize(n);
+
+    int mi = S.triMat[tri];
+    F3 nmlMap = f3(0, 1, 0);
+    long texW = 0, texH = 0, nmlW = 0, nmlH = 0;
+    int texFmt = MIPT_TEXFMT_NONE, nmlFmt = MIPT_TEXFMT_NONE;
+    uint64_t texOff = 0, nmlOff = 0;
+    F3 diffuse = f3(0, 0, 0);
+    if (mi >= 0) {
+        const DevMaterial& M = S.mats[mi];
+        texW = M.texW; texH = M.texH; texFmt = M.texFmt; texOff = M.texOffset;
+        nmlW = M.nmlW; nmlH = M.nmlH; nmlFmt = M.nmlFmt; nmlOff = M.nmlOffset;
+        diffuse = f3(M.diffuse[0], M.diffuse[1], M.diffuse[2]);
+    }
+    u = wrap01(u); v = wrap01(v);
+    if (nmlFmt != MIPT_TEXFMT_NONE && (R.useNormals)) {      // the map only matters when it is applied
+        long jn = (long)(nmlW * v), hn = (long)(nmlH * u);    // :303-306
+        jn = jn < nmlW - 1 ? jn : nmlW - 1;
+        hn = hn < nmlH - 1 ? hn : nmlH - 1;
+        uint32_t dw = fetch_texel_bgr(S, nmlFmt, nmlOff, hn * nmlW + jn);
+        float x = (float)(dw & 255u), y = (float)((dw >> 8) & 255u), z = (float)((dw >> 16) & 255u);
+        nmlMap.x = 2 * z / 255.0f - 1;                        // :315-317
+        nmlMap.y = (2 * x / 255.0f - 1);
+        nmlMap.z = 2 * y / 255.0f - 1;
+        if (R.normalizeNormalMap) nmlMap = f3normalize(nmlMap);
+    }
+    if (!R.useTextures) {
+        sf.albedo = f3(0.5f, 0.5f, 0.5f);                     // :320-326
+    } else if (texFmt != MIPT_TEXFMT_NONE && texW > 0) {
+        long j = (long)(texW * v), h = (long)(texH * u);      // :296-299
+        j = j < texW - 1 ? j : texW - 1;
+        h = h < texH - 1 ? h : texH - 1;
+        uint32_t dw = fetch_texel_bgr(S, texFmt, texOff, h * texW + j);
+        sf.albedo = f3((float)(dw & 255u) / 255.0f, (float)((dw >> 8) & 255u) / 255.0f, (float)((dw >> 16) & 255u) / 255.0f);
+    } else {
+        sf.albedo = diffuse;                                  // :338
+    }
+    coordinate_system(sf.N, sf.Nt, sf.Nb);                    // :389
+    if (R.useNormals) {                                       // :390-400
+        F3 nn = to_world(nmlMap, sf.N, sf.Nt, sf.Nb);
+        sf.N = f3normalize(nn);
+        coordinate_system(sf.N, sf.Nt, sf.Nb);
+    }
+    return sf;
+}
+
+// direct term before the shadow test and the shadow ray, CPUPathTracer.cpp:373-375,402-409
+__device__ __forceinline__ float direct_term(const DevRender& R, const Surface& sf, F3& so, F3& sd)
+{
+    F3 sun = f3(R.sun[0], R.sun[1], R.sun[2]);
+    sd = f3normalize(f3sub(sun, sf.hp));
+    so = f3add(sf.hp, f3scale(sf.N, PT_BIAS));
+    float dp = f3dot(sf.N, sd);
+    return R.sunIntensity * ((0.0f > dp) ? 0.0f : dp);
+}
+
+__device__ __forceinline__ bool pixel_owned(const DevRender& R, int p)
+{
+    if (R.shardCount <= 1) return true;
+    int x = p % R.W, y = p / R.W;
+    int tile = (y / R.tileSize) * R.tilesX + (x / R.tileSize);
+    return (tile % R.shardCount) == R.shardRank;
+}
+
+// pixState layout (4 float4 per pixel):
+//   [0] = (direct term D0, albedo.xyz)   [1] = (hitpoint.xyz, 1 if hit)
+//   [2] = (N.xyz, Nt.x)                  [3] = (Nt.y, Nt.z, 0, 0)
+__global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, const float4* __restrict__ hit,
+                                                      float4* pixState, int32_t* triIdImage, RayQueue shadowQ,
+                                                      int32_t* shadowCount, int32_t* actPix, int32_t* actCount)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = R.W * R.H;
+    bool inRange = p < n;
+    float4 h = inRange ? hit[p] : make_float4(0, 0, 0, __int_as_float(-1));
+    int tri = __float_as_int(h.w);
+    bool isHit = inRange && tri >= 0;
+    F3 so = f3(0, 0, 0), sd = f3(0, 0, 0);
+    if (inRange) triIdImage[p] = tri;
+    if (isHit) {
+        Surface sf = surface_at(S, R, tri, h.y, h.z);
+        float D = direct_term(R, sf, so, sd);
+        pixState[(size_t)p * 4 + 0] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
+        pixState[(size_t)p * 4 + 1] = make_float4(sf.hp.x, sf.hp.y, sf.hp.z, 1.0f);
+        pixState[(size_t)p * 4 + 2] = make_float4(sf.N.x, sf.N.y, sf.N.z, sf.Nt.x);
+        pixState[(size_t)p * 4 + 3] = make_float4(sf.Nt.y, sf.Nt.z, 0.0f, 0.0f);
+    } else if (inRange) {
+        pixState[(size_t)p * 4 + 0] = make_float4(0, 0, 0, 0);
+        pixState[(size_t)p * 4 + 1] = make_float4(0, 0, 0, 0);
+    }
+    int si = wave_append(isHit, shadowCount);
+    if (isHit) {
+        shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(p));
+        shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(0));
+    }
+    bool active = isHit && R.gi && pixel_owned(R, p);
+    int ai = wave_append(active, actCount);
+    if (active) actPix[ai] = p;
+}
+
+void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* hit, float4* pixState,
+                          int32_t* triIdImage, RayQueue shadowQ, int32_t* d_shadowCount, int32_t* actPix,
+                          int32_t* d_actCount, hipStream_t s)
+{
+    int n = R.W * R.H;
+    hipLaunchKernelGGL(k_shade_primary, dim3((n + 255) / 256), dim3(256), 0, s, S, R, hit, pixState, triIdImage, shadowQ,
+                       d_shadowCount, actPix, d_actCount);
+}
+
+// ---------------------------------------------------------------------------------------
+// first-bounce rays, CPUPathTracer.cpp:417-428 at depth 0: slot = s * nAct + a
+__global__ void __launch_bounds__(256) k_gen_first(DevRender R, const float4* __restrict__ pixState,
+                                                  const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
+                                                  int32_t Sn, RayQueue q)
+{
+    int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (int64_t)nAct * Sn) return;
+    int a = (int)(slot % nAct), s = (int)(slot / nAct);
+    int p = actPix[a];
+    uint32_t n = (uint32_t)(n0 + s);
+    float4 s1 = pixState[(size_t)p * 4 + 1], s2 = pixState[(size_t)p * 4 + 2], s3 = pixState[(size_t)p * 4 + 3];
+    F3 hp = f3(s1.x, s1.y, s1.z), N = f3(s2.x, s2.y, s2.z), Nt = f3(s2.w, s3.x, s3.y);
+    F3 Nb = f3cross(N, Nt);
+    float r1 = rng_u01(R.seed, (uint32_t)p, n, 0, 0), r2 = rng_u01(R.seed, (uint32_t)p, n, 0, 1);
+    F3 sw = to_world(sample_hemisphere(r1, r2), N, Nt, Nb);
+    F3 o = f3add(hp, f3scale(sw, PT_BIAS));
+    q.o[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
+    q.d[slot] = make_float4(sw.x, sw.y, sw.z, 0.0f);
+}
+
+void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const int32_t* actPix, int32_t nAct,
+                             int32_t n0, int32_t Sn, RayQueue q, hipStream_t s)
+{
+    int64_t n = (int64_t)nAct * Sn;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gen_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, R, pixState, actPix, nAct, n0, Sn, q);
+}
+
+// ---------------------------------------------------------------------------------------
+// Bounce shading (Radiance at depth `level`, 1..3).  pathState[(level-1)*slots + slot] =
+// (direct term, albedo.xyz); it stays zero for a path that ended before this level.
+__global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, RayQueue q, const float4* __restrict__ hit,
+                                                     const int32_t* __restrict__ d_count, int32_t level,
+                                                     const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
+                                                     float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
+                                                     int32_t* shadowCount, RayQueue nextQ, int32_t* nextCount)
+{
+    const int n = *d_count;
+    const int stride = gridDim.x * blockDim.x;
+    // every wave runs the same number of rounds so that the wave-wide appends see all lanes
+    const int rounds = (n + stride - 1) / stride;
+    for (int r = 0; r < rounds; r++) {
+        int i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool inRange = i < n;
+        float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
+        int tri = __float_as_int(h.w);
+        bool isHit = inRange && tri >= 0;
+        int slot = 0;
+        F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0);
+        bool spawn = isHit && (level < 3);     // a sample drawn at depth 3 is not traced (PathTracer.cu:380)
+        if (isHit) {
+            slot = __float_as_int(q.o[i].w);
+            Surface sf = surface_at(S, R, tri, h.y, h.z);
+            float D = direct_term(R, sf, so, sd);
+            pathState[(size_t)(level - 1) * slotsPerLevel + slot] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
+            if (spawn) {
+                int a = slot % nAct, s = slot / nAct;
+                uint32_t p = (uint32_t)actPix[a], smp = (uint32_t)(n0 + s);
+                float r1 = rng_u01(R.seed, p, smp, (uint32_t)level, 0), r2 = rng_u01(R.seed, p, smp, (uint32_t)level, 1);
+                nd = to_world(sample_hemisphere(r1, r2), sf.N, sf.Nt, sf.Nb);
+                no = f3add(sf.hp, f3scale(nd, PT_BIAS));
+            }
+        }
+        int si = wave_append(isHit, shadowCount);
+        if (isHit) {
+            shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
+            shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
+        }
+        if (level < 3) {
+            int ni = wave_append(spawn, nextCount);
+            if (spawn) {
+                nextQ.o[ni] = make_float4(no.x, no.y, no.z, __int_as_float(slot));
+                nextQ.d[ni] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            }
+        }
+    }
+}
+
+void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
+                         const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
+                         int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
+                         int32_t* d_shadowCount, RayQueue nextQ, int32_t* d_nextCount, hipStream_t s)
+{
+    if (maxCount <= 0) return;
+    long long blocks = ((long long)maxCount + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;      // grid-stride beyond this
+    hipLaunchKernelGGL(k_shade_bounce, dim3((unsigned)blocks), dim3(256), 0, s, S, R, q, hit, d_count, level, actPix, nAct, n0,
+                       pathState, slotsPerLevel, shadowQ, d_shadowCount, nextQ, d_nextCount);
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward resolve of one pass.  For sample n of pixel p, with c_k the first random number
+// drawn at depth k and (D_k, A_k) the stored state:
+//   L_4 = 0;  L_k = min(1, ((D_k + I * ((c_k * L_{k+1}) / pdf)) * A_k) / pi)   k = 3, 2, 1
+// (PathTracer.cu:449-462 with N = 1), and the pixel's running sum gains (c_0 * L_1) / pdf
+// in sample order (PathTracer.cu:449-451 at depth 0).
+__device__ __forceinline__ float min1(float x) { return (x < 1.0f) ? x : 1.0f; }
+
+__global__ void __launch_bounds__(256) k_resolve(DevRender R, const float4* __restrict__ pathState, int64_t slotsPerLevel,
+                                                const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0, int32_t Sn,
+                                                float4* pixAccum)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nAct) return;
+    uint32_t p = (uint32_t)actPix[a];
+    const float pdf = 1 / (2 * PT_PI);
+    const float I = R.sunIntensity;
+    float4 acc = pixAccum[a];
+    for (int s = 0; s < Sn; s++) {
+        uint32_t smp = (uint32_t)(n0 + s);
+        size_t slot = (size_t)s * nAct + a;
+        F3 L = f3(0, 0, 0);
+        #pragma unroll
+        for (int level = 3; level >= 1; level--) {
+            float4 st = pathState[(size_t)(level - 1) * slotsPerLevel + slot];
+            float c = rng_u01(R.seed, p, smp, (uint32_t)level, 0);
+            F3 ind = f3(c * L.x / pdf, c * L.y / pdf, c * L.z / pdf);
+            L.x = min1((st.x + I * ind.x) * st.y / PT_PI);
+            L.y = min1((st.x + I * ind.y) * st.z / PT_PI);
+            L.z = min1((st.x + I * ind.z) * st.w / PT_PI);
+        }
+        float c0 = rng_u01(R.seed, p, smp, 0, 0);
+        acc.x = acc.x + c0 * L.x / pdf;
+        acc.y = acc.y + c0 * L.y / pdf;
+        acc.z = acc.z + c0 * L.z / pdf;
+    }
+    pixAccum[a] = acc;
+}
+
+void launch_resolve(const DevRender& R, const float4* pathState, int64_t slotsPerLevel, const int32_t* actPix,
+                    int32_t nAct, int32_t n0, int32_t Sn, float4* pixAccum, hipStream_t s)
+{
+    if (nAct <= 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3((nAct + 255) / 256), dim3(256), 0, s, R, pathState, slotsPerLevel, actPix, nAct, n0, Sn, pixAccum);
+}
+
+__global__ void __launch_bounds__(256) k_scatter_accum(const float4* __restrict__ pixAccum, const int32_t* __restrict__ actPix,
+                                                      int32_t nAct, float* accum)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nAct) return;
+    size_t p = (size_t)actPix[a];
+    float4 v = pixAccum[a];
+    accum[3 * p] = v.x; accum[3 * p + 1] = v.y; accum[3 * p + 2] = v.z;
+}
+void launch_scatter_accum(const float4* pixAccum, const int32_t* actPix, int32_t nAct, float* d_accum, hipStream_t s)
+{
+    if (nAct <= 0) return;
+    hipLaunchKernelGGL(k_scatter_accum, dim3((nAct + 255) / 256), dim3(256), 0, s, pixAccum, actPix, nAct, d_accum);
+}
+
+// PathTracer.cu:453-462 and 550-552 at depth 0
+__global__ void __launch_bounds__(256) k_finalize(DevRender R, const float4* __restrict__ pixState, const float* __restrict__ accum,
+                                                 float* out)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= R.W * R.H) return;
+    float4 s0 = pixState[(size_t)p * 4 + 0], s1 = pixState[(size_t)p * 4 + 1];
+    F3 rgb = f3(0, 0, 0);
+    if (s1.w != 0.0f) {
+        F3 ind = f3(0, 0, 0);
+        if (R.gi) {
+            uint32_t N = (uint32_t)R.numSamples;
+            ind = f3(accum[3 * (size_t)p] / N, accum[3 * (size_t)p + 1] / N, accum[3 * (size_t)p + 2] / N);
+        }
+        rgb.x = (s0.x + R.sunIntensity * ind.x) * s0.y / PT_PI;
+        rgb.y = (s0.x + R.sunIntensity * ind.y) * s0.z / PT_PI;
+        rgb.z = (s0.x + R.sunIntensity * ind.z) * s0.w / PT_PI;
+    }
+    out[3 * (size_t)p] = 255 * min1(rgb.x);
+    out[3 * (size_t)p + 1] = 255 * min1(rgb.y);
+    out[3 * (size_t)p + 2] = 255 * min1(rgb.z);
+}
+void launch_finalize(const DevRender& R, const float4* pixState, const float* d_accum, float* d_out, hipStream_t s)
+{
+    int n = R.W * R.H;
+    hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, R, pixState, d_accum, d_out);
+}

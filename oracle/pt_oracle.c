@@ -683,3 +683,129 @@ int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p,
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* The same estimator cut the way a multi-GPU run cuts it: pto_accumulate produces, for the
+ * pixels of one shard and the first-bounce samples [sample_begin, sample_end), the
+ * unclamped sum of r1 * L1 / pdf (the running value of indirectLighting at
+ * CPUPathTracer.cpp:429-431 before the division by N at :433-435); sums of different
+ * shards add; pto_finalize applies :433-444 and the *255 of :509 to the total. */
+static int pixel_owned(const mipt_params* p, long W, long j, long h)
+{
+    int count = p->shard_count > 1 ? p->shard_count : 1;
+    if (count == 1) return 1;
+    int ts = p->tile_size > 0 ? p->tile_size : 32;
+    long tilesX = (W + ts - 1) / ts;
+    long tile = (h / ts) * tilesX + (j / ts);
+    return (tile % count) == p->shard_rank;
+}
+
+/* depth-0 part of Radiance up to the sample loop: returns 0 on a miss */
+static int primary_surface(rctx* R, const mipt_camera* cam, long j, long h, f3* hitpoint, f3* N, f3* Nt, f3* Nb,
+                           f3* albedo, f3* direct)
+{
+    const mipt_params* P = R->p;
+    float o[3], d[3];
+    pto_primary_ray(cam, (int32_t)j, (int32_t)h, o, d);
+    f3 nmlMesh = { 0, 0, 0 }, nmlMap = { 0, 1, 0 };
+    *direct = f3_make(0, 0, 0);
+    if (!trace_full(R, f3_ld(o), f3_ld(d), 0, hitpoint, &nmlMesh, &nmlMap, albedo, NULL)) return 0;
+    f3 sunDir = f3_normalize(f3_sub(f3_ld(P->sun_pos), *hitpoint));
+    float n3[3], nt3[3], nb3[3];
+    f3 hn = nmlMesh;
+    f3_st(n3, hn); pto_create_coordinate_system(n3, nt3, nb3);
+    *Nt = f3_ld(nt3); *Nb = f3_ld(nb3);
+    if (P->use_normals) {
+        f3 m = nmlMap, nn;
+        nn.x = m.x * Nb->x + m.y * hn.x + m.z * Nt->x;
+        nn.y = m.x * Nb->y + m.y * hn.y + m.z * Nt->y;
+        nn.z = m.x * Nb->z + m.y * hn.z + m.z * Nt->z;
+        hn = f3_normalize(nn);
+        f3_st(n3, hn); pto_create_coordinate_system(n3, nt3, nb3);
+        *Nt = f3_ld(nt3); *Nb = f3_ld(nb3);
+    }
+    *N = hn;
+    f3 ig1, ig2, ig3, ig4;
+    if (!trace_full(R, f3_add(*hitpoint, f3_scale(hn, 0.01f)), sunDir, 1, &ig1, &ig2, &ig3, &ig4, NULL)) {
+        float dp = f3_dot(hn, sunDir);
+        float l = P->sun_intensity * ((0.0f > dp) ? 0.0f : dp);
+        *direct = f3_make(l, l, l);
+    }
+    return 1;
+}
+
+int pto_accumulate(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel, float* out_accum, int threads)
+{
+    if (!s || !cam || !p || !out_accum || cam->div <= 0) return -1;
+    long W = cam->client_width / cam->div, H = cam->client_height / cam->div;
+    long ns = p->num_samples < 1 ? 1 : (p->num_samples > 10000 ? 10000 : p->num_samples);
+    long sb = p->sample_begin, se = p->sample_end;
+    if (sb == 0 && se == 0) se = ns;
+#ifdef _OPENMP
+    int nt = threads > 0 ? threads : omp_get_max_threads();
+#else
+    int nt = 1; (void)threads;
+#endif
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (long h = 0; h < H; ++h) {
+        rctx R; R.s = s; R.p = p; R.accel = accel; R.closest = R.shadow = R.tri_tests = R.box_tests = 0;
+        for (long j = 0; j < W; ++j) {
+            size_t idx = (size_t)(h * W + j);
+            f3 sum = { 0, 0, 0 };
+            f3 hp, N, Nt, Nb, albedo, direct;
+            if (p->global_illumination && pixel_owned(p, W, j, h) && primary_surface(&R, cam, j, h, &hp, &N, &Nt, &Nb, &albedo, &direct)) {
+                float pdf = 1 / (2 * PTO_PI);
+                for (long n = sb; n < se; ++n) {
+                    float r1 = pto_rng_u01(p->seed, (uint32_t)idx, (uint32_t)n, 0, 0);
+                    float r2 = pto_rng_u01(p->seed, (uint32_t)idx, (uint32_t)n, 0, 1);
+                    float smp[3];
+                    pto_uniform_sample_hemisphere(r1, r2, smp);
+                    f3 sw;
+                    sw.x = smp[0] * Nb.x + smp[1] * N.x + smp[2] * Nt.x;
+                    sw.y = smp[0] * Nb.y + smp[1] * N.y + smp[2] * Nt.y;
+                    sw.z = smp[0] * Nb.z + smp[1] * N.z + smp[2] * Nt.z;
+                    f3 rd = radiance(&R, 1, f3_add(hp, f3_scale(sw, 0.01f)), sw, 1, (uint32_t)idx, (uint32_t)n, NULL);
+                    sum.x = sum.x + r1 * rd.x / pdf;
+                    sum.y = sum.y + r1 * rd.y / pdf;
+                    sum.z = sum.z + r1 * rd.z / pdf;
+                }
+            }
+            out_accum[3 * idx] = sum.x; out_accum[3 * idx + 1] = sum.y; out_accum[3 * idx + 2] = sum.z;
+        }
+    }
+    return 0;
+}
+
+int pto_finalize(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel, const float* accum,
+                 float* out_bgr255, int threads)
+{
+    if (!s || !cam || !p || !accum || !out_bgr255 || cam->div <= 0) return -1;
+    long W = cam->client_width / cam->div, H = cam->client_height / cam->div;
+    uint32_t N = (uint32_t)(p->num_samples < 1 ? 1 : (p->num_samples > 10000 ? 10000 : p->num_samples));
+#ifdef _OPENMP
+    int nt = threads > 0 ? threads : omp_get_max_threads();
+#else
+    int nt = 1; (void)threads;
+#endif
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (long h = 0; h < H; ++h) {
+        rctx R; R.s = s; R.p = p; R.accel = accel; R.closest = R.shadow = R.tri_tests = R.box_tests = 0;
+        for (long j = 0; j < W; ++j) {
+            size_t idx = (size_t)(h * W + j);
+            f3 rgb = { 0, 0, 0 };
+            f3 hp, Nn, Nt, Nb, albedo, direct;
+            if (primary_surface(&R, cam, j, h, &hp, &Nn, &Nt, &Nb, &albedo, &direct)) {
+                f3 ind = { 0, 0, 0 };
+                if (p->global_illumination) {
+                    ind.x = accum[3 * idx] / N; ind.y = accum[3 * idx + 1] / N; ind.z = accum[3 * idx + 2] / N;
+                }
+                rgb.x = (direct.x + p->sun_intensity * ind.x) * albedo.x / PTO_PI;
+                rgb.y = (direct.y + p->sun_intensity * ind.y) * albedo.y / PTO_PI;
+                rgb.z = (direct.z + p->sun_intensity * ind.z) * albedo.z / PTO_PI;
+            }
+            rgb.x = (rgb.x < 1.0f) ? rgb.x : 1.0f; rgb.y = (rgb.y < 1.0f) ? rgb.y : 1.0f; rgb.z = (rgb.z < 1.0f) ? rgb.z : 1.0f;
+            out_bgr255[3 * idx] = 255 * rgb.x; out_bgr255[3 * idx + 1] = 255 * rgb.y; out_bgr255[3 * idx + 2] = 255 * rgb.z;
+        }
+    }
+    return 0;
+}

@@ -97,6 +97,16 @@ int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p,
                float* out_bgr255, uint32_t* out_dword, int32_t* out_tri,
                int32_t row_step, int32_t row_phase, int threads, pto_stats* stats);
 
+/* The estimator cut the way a multi-GPU run cuts it.  pto_accumulate: for the pixels of shard
+ * (p->shard_rank of p->shard_count, square tiles dealt round-robin) and the first-bounce samples
+ * [p->sample_begin, p->sample_end), the unclamped sum of r1 * L1 / pdf (CPUPathTracer.cpp:
+ * 429-431), zero elsewhere; sums of different shards add.  pto_finalize applies
+ * CPUPathTracer.cpp:433-444 and the *255 of :509 to the total. */
+int pto_accumulate(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel,
+                   float* out_accum, int threads);
+int pto_finalize(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel,
+                 const float* accum, float* out_bgr255, int threads);
+
 #ifdef __cplusplus
 }
 #endif

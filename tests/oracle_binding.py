@@ -1,0 +1,159 @@
+"""ctypes binding of oracle/libpt_oracle.so.  Test infrastructure: imported by tests,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_ROOT, "cuda-path-tracer_amd"))
+from mipt import abi  # noqa: E402
+
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libpt_oracle.so")
+ACCEL_OCTREE, ACCEL_BRUTE = 0, 1
+
+
+class Hit(C.Structure):
+    _fields_ = [("tri", C.c_int32), ("t", C.c_float), ("ua", C.c_float), ("va", C.c_float), ("u", C.c_float),
+                ("v", C.c_float), ("hitpoint", C.c_float * 3), ("normal", C.c_float * 3), ("mesh", C.c_int32)]
+
+
+class OStats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
+                ("box_tests", C.c_uint64), ("seconds", C.c_double), ("threads", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        L = C.CDLL(ORACLE_LIB)
+        F3 = C.POINTER(C.c_float)
+        L.pto_intersect_ray_triangle.argtypes = [F3, F3, F3, F3, F3, C.c_float, F3, F3, F3]
+        L.pto_intersect_ray_aabb.argtypes = [F3, F3, F3, F3, F3]
+        L.pto_point_in_aabb.argtypes = [F3, F3, F3]
+        L.pto_uniform_sample_hemisphere.argtypes = [C.c_float, C.c_float, F3]
+        L.pto_create_coordinate_system.argtypes = [F3, F3, F3]
+        L.pto_rng_u01.restype = C.c_float
+        L.pto_rng_u01.argtypes = [C.c_uint32] * 5
+        L.pto_primary_ray.argtypes = [C.POINTER(abi.Camera), C.c_int32, C.c_int32, F3, F3]
+        L.pto_scene_create.restype = C.c_void_p
+        L.pto_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
+        L.pto_scene_destroy.argtypes = [C.c_void_p]
+        L.pto_scene_num_triangles.restype = C.c_int64
+        L.pto_scene_num_triangles.argtypes = [C.c_void_p]
+        L.pto_scene_octree_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.pto_trace.argtypes = [C.c_void_p, F3, F3, C.c_float, C.c_int, C.POINTER(Hit)]
+        L.pto_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int]
+        L.pto_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(OStats)]
+        L.pto_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p, C.c_int]
+        L.pto_finalize.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def f3(*v):
+    return (C.c_float * 3)(*v)
+
+
+def intersect_ray_triangle(o, d, v0, v1, v2, eps=1e-20):
+    t, u, v = C.c_float(), C.c_float(), C.c_float()
+    hit = lib().pto_intersect_ray_triangle(f3(*o), f3(*d), f3(*v0), f3(*v1), f3(*v2), eps, C.byref(t), C.byref(u), C.byref(v))
+    return bool(hit), t.value, u.value, v.value
+
+
+def intersect_ray_aabb(o, d, center, extents):
+    dist = C.c_float()
+    hit = lib().pto_intersect_ray_aabb(f3(*o), f3(*d), f3(*center), f3(*extents), C.byref(dist))
+    return bool(hit), dist.value
+
+
+def rng_u01(seed, pixel, sample, depth, dim):
+    return lib().pto_rng_u01(seed, pixel, sample, depth, dim)
+
+
+def primary_ray(cam, j, h):
+    o, d = f3(0, 0, 0), f3(0, 0, 0)
+    lib().pto_primary_ray(C.byref(cam), j, h, o, d)
+    return np.array(o[:], dtype=np.float32), np.array(d[:], dtype=np.float32)
+
+
+class OracleScene:
+    def __init__(self, desc_ptr):
+        self._h = C.c_void_p(lib().pto_scene_create(desc_ptr))
+
+    @property
+    def num_triangles(self):
+        return lib().pto_scene_num_triangles(self._h)
+
+    def octree_info(self):
+        n, d, l = C.c_int64(), C.c_int32(), C.c_int64()
+        lib().pto_scene_octree_info(self._h, C.byref(n), C.byref(d), C.byref(l))
+        return n.value, d.value, l.value
+
+    def trace(self, o, d, eps=1e-20, accel=ACCEL_BRUTE):
+        h = Hit()
+        hit = lib().pto_trace(self._h, f3(*o), f3(*d), eps, accel, C.byref(h))
+        return bool(hit), h
+
+    def trace_rays(self, rays, eps=1e-20, accel=ACCEL_BRUTE, threads=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        tri = np.empty(n, dtype=np.int32)
+        tuv = np.empty((n, 3), dtype=np.float32)
+        anyhit = np.empty(n, dtype=np.uint8)
+        lib().pto_trace_rays(self._h, rays.ctypes.data, n, eps, accel, tri.ctypes.data, tuv.ctypes.data,
+                             anyhit.ctypes.data, threads)
+        return tri, tuv, anyhit
+
+    def render(self, cam, params, accel=ACCEL_OCTREE, row_step=1, row_phase=0, threads=0):
+        w, h = cam.image_size
+        img = np.zeros((h, w, 3), dtype=np.float32)
+        dword = np.zeros((h, w), dtype=np.uint32)
+        tri = np.full((h, w), -2, dtype=np.int32)
+        st = OStats()
+        rc = lib().pto_render(self._h, C.byref(cam), C.byref(params), accel, img.ctypes.data, dword.ctypes.data,
+                              tri.ctypes.data, row_step, row_phase, threads, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("pto_render failed")
+        return img, dword, tri, st
+
+    def accumulate(self, cam, params, accel=ACCEL_OCTREE, threads=0):
+        w, h = cam.image_size
+        acc = np.zeros((h, w, 3), dtype=np.float32)
+        if lib().pto_accumulate(self._h, C.byref(cam), C.byref(params), accel, acc.ctypes.data, threads) != 0:
+            raise RuntimeError("pto_accumulate failed")
+        return acc
+
+    def finalize(self, cam, params, accum, accel=ACCEL_OCTREE, threads=0):
+        w, h = cam.image_size
+        accum = np.ascontiguousarray(accum, dtype=np.float32)
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        if lib().pto_finalize(self._h, C.byref(cam), C.byref(params), accel, accum.ctypes.data, out.ctypes.data, threads) != 0:
+            raise RuntimeError("pto_finalize failed")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pto_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,124 @@
+"""Structure checks of the GPU-built BVH (downloaded through the C ABI), run before any
+traversal test: a malformed tree must show up here, not as a hung kernel."""
+import numpy as np
+import pytest
+
+from mipt import abi, host
+
+pytestmark = pytest.mark.gpu
+
+LEAF = 0x80000000
+
+
+def validate_bvh(scene_host, dev_scene):
+    info = dev_scene.info()
+    nodes, v0, e1, e2, root = dev_scene.download_bvh()
+    verts = scene_host.vertices()[:, :, :3]
+    n = scene_host.num_triangles
+    assert info.num_triangles == n and v0.shape[0] == n
+    ids = v0[:, 3].copy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(np.sort(ids), np.arange(n)), "every triangle must sit in exactly one leaf slot"
+    # leaf slots hold v0 and the fp32 edge differences of the input, bit for bit
+    p0, p1, p2 = verts[ids, 0], verts[ids, 1], verts[ids, 2]
+    assert np.array_equal(v0[:, :3], p0)
+    assert np.array_equal(e1[:, :3], p1 - p0) and np.array_equal(e2[:, :3], p2 - p0)
+    last = e1[:, 3].copy().view(np.uint32)
+    assert set(np.unique(last)) <= {0, 1} and last[-1] == 1
+    tri_lo = np.minimum(np.minimum(p0, p1), p2)
+    tri_hi = np.maximum(np.maximum(p0, p1), p2)
+    codes = nodes[:, 12:14].copy().view(np.uint32)
+    seen = np.zeros(n, dtype=bool)
+    max_depth = 0
+    leaves = 0
+    inner = 0
+    if root == 0xFFFFFFFF:
+        assert n == 0
+        return info
+    stack = [(int(root), 0, None, None)]
+    while stack:
+        code, depth, lo, hi = stack.pop()
+        max_depth = max(max_depth, depth)
+        if code & LEAF:
+            s = code & 0x7FFFFFFF
+            e = s
+            while last[e] == 0:
+                e += 1
+            sl = slice(s, e + 1)
+            assert not seen[sl].any(), "leaf ranges overlap"
+            seen[sl] = True
+            leaves += 1
+            if lo is not None:      # the parent's (padded) box of this child contains the leaf's triangles
+                assert (tri_lo[sl] >= lo).all() and (tri_hi[sl] <= hi).all()
+            continue
+        inner += 1
+        nd = nodes[code]
+        boxes = [(nd[0:3], np.array([nd[3], nd[4], nd[5]])), (np.array([nd[6], nd[7], nd[8]]), nd[9:12])]
+        for k in range(2):
+            clo, chi = boxes[k]
+            assert (clo <= chi).all()
+            if lo is not None:      # nested up to the padding both levels carry
+                assert (clo >= lo - 1e-6 * np.abs(lo) - 1e-30).all() and (chi <= hi + 1e-6 * np.abs(hi) + 1e-30).all()
+            stack.append((int(codes[code, k]), depth + 1, clo, chi))
+    assert seen.all(), "some leaf slot is unreachable from the root"
+    assert max_depth == info.max_depth and leaves == info.num_leaves and inner == info.num_nodes
+    assert info.max_depth + 2 <= 640
+    return info
+
+
+def test_bvh_cornell(gpu, cornell):
+    sc = gpu.Scene(cornell.desc)
+    info = validate_bvh(cornell, sc)
+    assert info.num_triangles == 32 and info.num_leaves >= 8
+
+
+def test_bvh_atrium_small(gpu, atrium_small):
+    sc = gpu.Scene(atrium_small.desc)
+    info = validate_bvh(atrium_small, sc)
+    assert info.num_leaves * 4 >= info.num_triangles          # leaves hold at most 4 triangles unless centroids coincide
+    assert info.sah_cost > 0
+
+
+def test_bvh_degenerate_inputs(gpu):
+    # one triangle; many identical triangles (coincident centroids force splits by position);
+    # zero-area and sliver triangles; an empty scene
+    def scene_from(tris):
+        tris = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+        n = tris.shape[0]
+        v = np.zeros((n, 3, 8), dtype=np.float32)
+        v[:, :, :3] = tris
+        v[:, :, 4] = 1.0
+        verts = (abi.Vertex * (3 * n)).from_buffer_copy(v.tobytes()) if n else None
+        mesh = (abi.Mesh * 1)(abi.Mesh(0, n, -1, 0))
+        desc = abi.SceneDesc()
+        import ctypes as C
+        desc.vertices = C.cast(verts, C.POINTER(abi.Vertex)) if n else None
+        desc.num_triangles = n
+        desc.meshes = C.cast(mesh, C.POINTER(abi.Mesh))
+        desc.num_meshes = 1
+        desc.num_materials = 0
+        return desc, (verts, mesh)
+
+    import ctypes as C
+    one = [[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]
+    desc, keep = scene_from(one)
+    sc = gpu.Scene(C.pointer(desc))
+    tri, tuv, anyhit = sc.trace_rays(np.array([[0.2, 0.2, 1, 0, 0, -1], [2, 2, 1, 0, 0, -1]], dtype=np.float32))
+    assert tri.tolist() == [0, -1] and anyhit.tolist() == [1, 0] and tuv[0].tolist() == [1.0, 0.2, 0.2]
+
+    same = one * 100
+    desc, keep = scene_from(same)
+    sc = gpu.Scene(C.pointer(desc))
+    assert sc.info().num_triangles == 100
+    tri, _, _ = sc.trace_rays(np.array([[0.2, 0.2, 1, 0, 0, -1]], dtype=np.float32))
+    assert tri.tolist() == [0]                       # 100 exact ties: the lowest id wins
+
+    odd = one + [[[0, 0, 0], [1, 1, 0], [2, 2, 0]], [[0, 0, -1], [1, 0, -1], [1, 1e-7, -1]], [[5, 5, 5], [5, 5, 5], [5, 5, 5]]]
+    desc, keep = scene_from(odd)
+    sc = gpu.Scene(C.pointer(desc))
+    tri, _, _ = sc.trace_rays(np.array([[0.2, 0.2, 1, 0, 0, -1]], dtype=np.float32))
+    assert tri.tolist() == [0]
+
+    desc, keep = scene_from(np.zeros((0, 3, 3)))
+    sc = gpu.Scene(C.pointer(desc))
+    tri, _, anyhit = sc.trace_rays(np.array([[0.2, 0.2, 1, 0, 0, -1]], dtype=np.float32))
+    assert tri.tolist() == [-1] and anyhit.tolist() == [0]

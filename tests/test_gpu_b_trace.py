@@ -1,0 +1,78 @@
+"""Closest-hit and any-hit parity of the HIP traversal against the CPU oracle's brute-force
+search, through mipt_trace_rays.  Integer results (triangle ids, any-hit flags) and the
+fp32 (t, u, v) of the winning triangle must be identical bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenes
+from conftest import GOLDEN
+from mipt import abi, host
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_trace_parity(dev_scene, oracle_scene, rays, eps=1e-20):
+    tri, tuv, anyhit = dev_scene.trace_rays(rays, eps=eps)
+    otri, otuv, oany = oracle_scene.trace_rays(rays, eps=eps, accel=ob.ACCEL_BRUTE)
+    bad = np.nonzero(tri != otri)[0]
+    assert bad.size == 0, f"{bad.size} of {len(tri)} closest-hit ids differ, first: ray {bad[:5]}, gpu {tri[bad[:5]]}, oracle {otri[bad[:5]]}"
+    assert np.array_equal(anyhit, oany), f"{(anyhit != oany).sum()} any-hit flags differ"
+    assert np.array_equal(tuv.view(np.uint32), otuv.view(np.uint32)), "t/u/v differ in their bits"
+    return tri
+
+
+def test_golden_ray_batch(gpu, cornell):
+    g = np.load(os.path.join(GOLDEN, "cornell_rays_4096.npz"))
+    sc = gpu.Scene(cornell.desc)
+    tri, tuv, anyhit = sc.trace_rays(g["rays"])
+    assert np.array_equal(tri, g["tri"]) and np.array_equal(anyhit, g["anyhit"])
+    assert np.array_equal(tuv.view(np.uint32), g["tuv"].view(np.uint32))
+
+
+def test_cornell_random_and_aimed_rays(gpu, cornell, cornell_oracle):
+    sc = gpu.Scene(cornell.desc)
+    tri = assert_trace_parity(sc, cornell_oracle, scenes.random_rays(cornell, 200000, seed=1))
+    assert (tri >= 0).mean() > 0.2
+    # both flavours of the determinant threshold (xnacollision.cpp:1073 vs PathTracer.cu:153)
+    assert_trace_parity(sc, cornell_oracle, scenes.random_rays(cornell, 50000, seed=2), eps=1e-5)
+
+
+def test_atrium_small_rays(gpu, atrium_small, atrium_small_oracle):
+    sc = gpu.Scene(atrium_small.desc)
+    tri = assert_trace_parity(sc, atrium_small_oracle, scenes.random_rays(atrium_small, 30000, seed=3))
+    assert (tri >= 0).mean() > 0.5
+
+
+def test_build_options_do_not_change_results(gpu, atrium_small, atrium_small_oracle):
+    rays = scenes.random_rays(atrium_small, 8000, seed=4)
+    for bins, leaf in [(4, 1), (32, 8), (8, 2)]:
+        sc = gpu.Scene(atrium_small.desc, sah_bins=bins, max_leaf_triangles=leaf)
+        assert_trace_parity(sc, atrium_small_oracle, rays)
+
+
+def test_atrium_262k_rays(gpu):
+    big = host.HostScene.atrium(abi.SCENE_CRYTEK, 262000, 0, 1)
+    osc = ob.OracleScene(big.desc)
+    sc = gpu.Scene(big.desc)
+    info = sc.info()
+    assert info.num_triangles == big.num_triangles
+    assert_trace_parity(sc, osc, scenes.random_rays(big, 3000, seed=7))
+
+
+def test_empty_and_ragged_batches(gpu, cornell, cornell_oracle):
+    sc = gpu.Scene(cornell.desc)
+    tri, tuv, anyhit = sc.trace_rays(np.zeros((0, 6), dtype=np.float32))
+    assert tri.size == 0
+    for n in (1, 63, 64, 65, 127, 1000):           # sizes around the 64-lane wave
+        assert_trace_parity(sc, cornell_oracle, scenes.random_rays(cornell, n, seed=100 + n))
+    # non-finite and zero directions must not hang or fault, and must agree with the oracle
+    rays = scenes.random_rays(cornell, 64, seed=9)
+    rays[0, 3:] = 0
+    rays[1, 3] = np.inf
+    rays[2, 0] = np.nan
+    rays[3, 3:] = [0, -1, 0]
+    rays[4, 3:] = [1e-38, -1, 0]
+    assert_trace_parity(sc, cornell_oracle, rays)

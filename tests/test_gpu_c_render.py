@@ -1,0 +1,170 @@
+"""Whole-render parity of the HIP wavefront pipeline against the CPU oracle, through the C ABI.
+
+ - primary-hit triangle ids: identical (ties -> lowest id)
+ - direct-light radiance: per-pixel relative error <= 1e-3 (in practice identical)
+ - GI: same counter-based random stream on both sides; image mean within 3 sigma of the Monte
+   Carlo error, RMSE reported and bounded
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenes
+from conftest import GOLDEN
+from mipt import abi, host
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3      # direct-light tolerance of the parity contract
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)      # images are scaled to 0..255
+
+
+def test_cornell_direct_golden_480x270(gpu, cornell):
+    g = np.load(os.path.join(GOLDEN, "cornell_direct_480x270.npz"))
+    cam, sun = scenes.cornell_camera(div=4)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=8)
+    sc = gpu.Scene(cornell.desc)
+    img, ids, st = sc.render(cam, prm)
+    assert np.array_equal(ids, g["tri"])
+    assert rel_err(img, g["bgr255"]).max() <= REL_TOL
+    assert np.array_equal(img, g["bgr255"])                 # the arithmetic is the same fp32 sequence
+    assert np.array_equal(host.pack_bgra(img).reshape(270, 480), g["dword"])
+    assert st.closest_rays == 480 * 270 and st.shadow_rays == int((ids >= 0).sum())
+
+
+def test_cornell_direct_full_resolution(gpu, cornell, cornell_oracle):
+    cam, sun = scenes.cornell_camera(div=1)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=64)
+    sc = gpu.Scene(cornell.desc)
+    img, ids, st = sc.render(cam, prm)
+    oimg, _, otri, _ = cornell_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids, otri)
+    assert rel_err(img, oimg).max() <= REL_TOL
+
+
+@pytest.mark.parametrize("use_textures,use_normals,nnm", [(1, 0, 0), (1, 1, 0), (0, 1, 1), (1, 1, 1)])
+def test_atrium_direct_textures_and_normal_maps(gpu, atrium_small, atrium_small_oracle, use_textures, use_normals, nnm):
+    cam, sun = scenes.crytek_camera(div=4)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, use_textures=use_textures, use_normals=use_normals,
+                              normalize_normal_map=nnm)
+    sc = gpu.Scene(atrium_small.desc)
+    img, ids, _ = sc.render(cam, prm)
+    oimg, _, otri, _ = atrium_small_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids, otri)
+    assert (ids >= 0).mean() > 0.9
+    assert rel_err(img, oimg).max() <= REL_TOL
+    assert img.max() > 10          # something is lit
+
+
+def gi_compare(img, oimg, n_samples):
+    diff = img.astype(np.float64) - oimg.astype(np.float64)
+    rmse = float(np.sqrt((diff ** 2).mean()))
+    # Monte Carlo standard error of the image mean, estimated from the oracle image itself: per-pixel
+    # values are independent estimates; the mean of P pixels has sigma = std / sqrt(P)
+    sigma = float(oimg.std() / np.sqrt(oimg.size))
+    return rmse, abs(float(img.mean() - oimg.mean())), sigma, float((img == oimg).mean())
+
+
+def test_cornell_gi_against_oracle(gpu, cornell, cornell_oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_gi16_240x135.npz"))
+    cam, sun = scenes.cornell_camera(div=8)
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=16)
+    sc = gpu.Scene(cornell.desc)
+    img, ids, st = sc.render(cam, prm)
+    assert np.array_equal(ids, g["tri"])
+    rmse, dmean, sigma, same = gi_compare(img, g["bgr255"], 16)
+    print(f"cornell GI N=16: rmse={rmse:.4g} |dmean|={dmean:.4g} sigma={sigma:.4g} identical={same:.4f}")
+    assert dmean <= 3 * sigma
+    assert rmse < 1.0              # same random stream: only sin/cos rounding separates the two sides
+    assert st.closest_rays + st.shadow_rays <= ids.size * (2 + 6 * 16)
+    assert st.closest_rays > ids.size
+
+
+def test_atrium_gi_against_oracle(gpu, atrium_small, atrium_small_oracle):
+    cam, sun = scenes.crytek_camera(div=8)
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=8, use_normals=1)
+    sc = gpu.Scene(atrium_small.desc)
+    img, ids, st = sc.render(cam, prm)
+    oimg, _, otri, ost = atrium_small_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids, otri)
+    rmse, dmean, sigma, same = gi_compare(img, oimg, 8)
+    print(f"atrium GI N=8: rmse={rmse:.4g} |dmean|={dmean:.4g} sigma={sigma:.4g} identical={same:.4f}")
+    assert dmean <= 3 * sigma
+    assert rmse < 2.0
+    # ray counts agree up to the few paths that bifurcate
+    assert abs(int(st.closest_rays) - int(ost.closest_rays)) <= 0.001 * ost.closest_rays
+
+
+def test_pass_size_does_not_change_the_image(gpu, cornell):
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    ref = None
+    for chunk in (0, 1, 3, 16):
+        prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=16, chunk_samples=chunk)
+        img, _, st = sc.render(cam, prm)
+        if ref is None:
+            ref = img
+        assert np.array_equal(img, ref), f"chunk_samples={chunk}"
+
+
+def test_tile_and_sample_shards_add_up(gpu, cornell):
+    """What bench.py does across GPUs, run sequentially on one: every shard accumulates into its own
+    buffer, the buffers are summed (the RCCL reduce), rank 0 finalizes."""
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    N = 12
+    full = host.default_params(sun_pos=sun, global_illumination=1, num_samples=N)
+    ref, _, _ = sc.render(cam, full)
+    npx = 240 * 135
+
+    def run(params_list):
+        total = np.zeros(npx * 3, dtype=np.float32)
+        frames = []
+        for p in params_list:
+            fr = gpu.Frame(sc, cam, p)
+            acc = gpu.DeviceBuffer(npx * 12)
+            fr.accumulate(acc.ptr)
+            total += acc.to_host()
+            frames.append(fr)
+        acc = gpu.DeviceBuffer(npx * 12)
+        out = gpu.DeviceBuffer(npx * 12)
+        acc.from_host(total)
+        frames[0].finalize(acc.ptr, out.ptr)
+        return out.to_host().reshape(135, 240, 3)
+
+    tiles = [host.default_params(sun_pos=sun, global_illumination=1, num_samples=N, shard_rank=r, shard_count=4, tile_size=16)
+             for r in range(4)]
+    assert np.array_equal(run(tiles), ref)                   # disjoint pixels: x + 0 is exact
+    halves = [host.default_params(sun_pos=sun, global_illumination=1, num_samples=N, sample_begin=a, sample_end=b)
+              for a, b in ((0, 5), (5, N))]
+    assert np.allclose(run(halves), ref, rtol=1e-5, atol=1e-3)   # partial sums: equal up to fp32 summation order
+
+
+def test_progress_callback_contract(gpu, cornell):
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    calls = []
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=8, chunk_samples=2)
+    sc.render(cam, prm, progress=lambda done, total, user: calls.append((done, total)))
+    total = 240 * 135
+    assert calls[0] == (0, total) and calls[-1] == (total, total)           # PathTracer.cu:721, 726-731
+    assert all(b[0] >= a[0] for a, b in zip(calls, calls[1:])) and len(calls) == 1 + 4
+
+
+def test_invalid_arguments_are_rejected(gpu, cornell):
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    bad = host.default_params(sun_pos=sun, shard_rank=3, shard_count=2)
+    with pytest.raises(gpu.MiptError):
+        sc.render(cam, bad)
+    bad = host.default_params(sun_pos=sun, num_samples=4, sample_begin=3, sample_end=9)
+    with pytest.raises(gpu.MiptError):
+        sc.render(cam, bad)
+    cam0 = abi.Camera.from_buffer_copy(bytes(cam)); cam0.div = 0
+    with pytest.raises(gpu.MiptError):
+        sc.render(cam0, host.default_params(sun_pos=sun))
