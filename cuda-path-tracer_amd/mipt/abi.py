@@ -32,6 +32,8 @@ class Camera(C.Structure):
 
     @property
     def image_size(self):
+        if self.div <= 0:
+            return 0, 0
         return self.client_width // self.div, self.client_height // self.div
 
 
