@@ -76,7 +76,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from mipt import abi, device, host
+    from mipt import abi, device, host, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,10 +96,7 @@ def main():
     dev = device.Scene(scene.desc)
     info = dev.info()
 
-    shard = dict(shard_rank=rank, shard_count=world, tile_size=32)
-    if args.shard == "samples" and world > 1:
-        per = (samples + world - 1) // world
-        shard = dict(sample_begin=min(samples, rank * per), sample_end=min(samples, (rank + 1) * per))
+    shard = sharding.shard_fields(rank, world, samples, args.shard)
     params = host.default_params(sun_pos=sun, global_illumination=gi, num_samples=samples, use_textures=1, use_normals=0,
                                  chunk_samples=args.chunk, **shard)
     frame = device.Frame(dev, cam, params)
@@ -109,8 +106,7 @@ def main():
 
     def step():
         st = frame.accumulate(accum.data_ptr())
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        sharding.reduce_to_rank0(accum, dist, world)
         if rank == 0:
             frame.finalize(accum.data_ptr(), out.data_ptr())
         return st

@@ -5,8 +5,8 @@
 // row-major, row-vector 4x4 type instead of DirectXMath, which is not available
 // outside the Windows SDK.  sin/cos come from libm; DirectXMath's XMScalarSinCos
 // polynomial is not reproduced, so matrices can differ from the reference's in the
-// last bits.  They are inputs to the render call: both the library and the oracle
-// receive the same numbers.
+// last bits.  They are inputs to the render call, pinned by value: every renderer that is
+// compared receives the same numbers.
 #pragma once
 #include <cmath>
 

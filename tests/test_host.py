@@ -1,0 +1,154 @@
+"""Host logic of the headless harness: OBJ/MTL reading, scene assembly, camera marshalling,
+the procedural atrium, PNG decoding, the 8-bit output stage."""
+import math
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import scenes
+from mipt import abi, host, sharding
+
+
+def test_camera_preset_matches_reference_numbers():
+    # RayTracerView.cpp:211: fovY = pi/4 -> P(1,1) = cot(pi/8), P(0,0) = P(1,1) / aspect
+    cam, sun = host.camera_preset(abi.SCENE_CRYTEK, 1920, 1080, 1)
+    assert abs(cam.p1 - 1 / math.tan(math.pi / 8)) < 1e-6 and abs(cam.p0 - cam.p1 * 1080 / 1920) < 1e-6
+    m = np.array(cam.to_local[:]).reshape(4, 4)
+    assert np.allclose(m[3], [-1280, 138, -50, 1])                      # eye position, :224
+    assert np.allclose(m[2, :3], [1, 0, 0], atol=1e-5)                  # look = +x after RotateY(3.1416/2), :225
+    assert np.allclose(sun, [0, 2000 * math.sin(0.45 * math.pi), 2000 * math.cos(0.45 * math.pi)], rtol=1e-6)
+    cam, sun = host.camera_preset(abi.SCENE_SPONZA, 1920, 1080, 2)
+    m = np.array(cam.to_local[:]).reshape(4, 4)
+    assert np.allclose(m[3, :3], [10, 5, 0]) and np.allclose(m[2, :3], [-1, 0, 0], atol=1e-5) and cam.image_size == (960, 540)
+    assert abs(sun[1] - 80 * math.sin(0.45 * math.pi)) < 1e-4
+    with pytest.raises(ValueError):
+        host.camera_preset(7, 1920, 1080, 1)
+    # to_local is the inverse of a rigid view matrix: orthonormal rotation part
+    r = m[:3, :3]
+    assert np.allclose(r @ r.T, np.eye(3), atol=1e-6)
+
+
+def test_default_params_follow_the_ui_defaults():
+    p = host.default_params()
+    assert (p.num_samples, p.global_illumination, p.use_textures, p.use_normals) == (16, 1, 1, 0)   # SideView.cpp:81-119
+    assert p.sun_intensity == 3.0 and abs(p.epsilon - 1e-20) < 1e-26 and p.seed == 0x5EED
+
+
+def test_obj_loader_features(tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl red\nKd 1 0 0\nnewmtl grey\nKd 0.5\nmap_Kd missing.png\nnewmtl tex\nKd 0.1 0.2 0.3\nmap_Kd t.png\nmap_Bump n.png\n")
+    # 2x2 RGB and 1x1 grey PNGs written by hand (filter type 0)
+    def png(path, w, h, ctype, rows):
+        raw = b"".join(b"\x00" + bytes(r) for r in rows)
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                         chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    png(tmp_path / "t.png", 2, 2, 2, [[255, 0, 0, 0, 255, 0], [0, 0, 255, 10, 20, 30]])
+    png(tmp_path / "n.png", 1, 1, 0, [[128]])
+    (tmp_path / "m.obj").write_text(
+        "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\nvn 0 0 1\n"
+        "f 1/1/1 2/2/1 3/3/1\n"                      # before any usemtl: belongs to no mesh (MainFrm.cpp:315)
+        "usemtl red\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"    # a quad: only its first three corners are used (:364-400)
+        "usemtl tex\nf 1/1/1 2/2/1 3/3/1\nf -3/-3/-1 -2/-2/-1 -1/-1/-1\nf 2/2/1 4/4/1 3/3/1\n"
+        "usemtl grey\nf 1/1/1 3/3/1 2/2/1\n")
+    s = host.HostScene.load_obj(str(tmp_path / "m.obj"))
+    d = s.desc.contents
+    # meshes sorted by triangle count, descending and stable: tex(3), red(1), grey(1)
+    assert [m[1] for m in s.meshes()] == [3, 1, 1]
+    # material "grey" names a diffuse map that does not load -> it is dropped (MainFrm.cpp:249-297): 2 materials remain
+    assert d.num_materials == 2
+    mats = [m[2] for m in s.meshes()]
+    assert mats == [1, 0, -1]
+    assert np.allclose(d.materials[0].diffuse[:], [0, 0, 1])            # Kd 1 0 0 stored BGR
+    t = d.materials[1]
+    assert (t.tex_width, t.tex_height, t.tex_format, t.nml_width, t.nml_height) == (2, 2, abi.MIPT_TEX_BGRA8, 1, 1)
+    tex = np.ctypeslib.as_array(C_cast_u32(t.tex_data), shape=(4,))
+    assert [hex(x) for x in tex] == ["0xffff0000", "0xff00ff00", "0xff0000ff", "0xff0a141e"]   # byte0 = blue
+    v = s.vertices()
+    assert np.allclose(v[3, :, :3], [[0, 0, 0], [1, 0, 0], [0, 1, 0]])  # the quad's first three corners
+    flipped = host.HostScene.load_obj(str(tmp_path / "m.obj"), flip_winding=True)
+    assert np.allclose(flipped.vertices()[3, :, :3], [[0, 0, 0], [0, 1, 0], [1, 0, 0]])
+    with pytest.raises(RuntimeError):
+        host.HostScene.load_obj(str(tmp_path / "absent.obj"))
+
+
+def C_cast_u32(ptr):
+    import ctypes as C
+    return C.cast(ptr, C.POINTER(C.c_uint32))
+
+
+def test_png_decoder_against_pil(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for mode, shape in (("RGB", (37, 53, 3)), ("RGBA", (16, 16, 4)), ("L", (31, 7))):
+        arr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        path = tmp_path / f"{mode}.png"
+        Image.fromarray(arr, mode).save(path)
+        got = host.load_png(str(path))
+        rgb = np.array(Image.open(path).convert("RGB")).astype(np.uint32)
+        want = rgb[..., 2] | (rgb[..., 1] << 8) | (rgb[..., 0] << 16) | (255 << 24)
+        assert np.array_equal(got, want), mode
+    pal = Image.fromarray(rng.integers(0, 256, size=(9, 9, 3), dtype=np.uint8), "RGB").convert("P", palette=Image.ADAPTIVE, colors=16)
+    pal.save(tmp_path / "p.png")
+    rgb = np.array(pal.convert("RGB")).astype(np.uint32)
+    assert np.array_equal(host.load_png(str(tmp_path / "p.png")), rgb[..., 2] | (rgb[..., 1] << 8) | (rgb[..., 0] << 16) | (255 << 24))
+    with pytest.raises(IOError):
+        host.load_png(str(tmp_path / "nope.png"))
+
+
+def test_atrium_is_deterministic_and_hits_its_budget():
+    a = host.HostScene.atrium(abi.SCENE_CRYTEK, 66000, 32, 1)
+    b = host.HostScene.atrium(abi.SCENE_CRYTEK, 66000, 32, 1)
+    assert abs(a.num_triangles - 66000) < 0.03 * 66000
+    assert a.num_triangles == b.num_triangles and np.array_equal(a.vertices(), b.vertices())
+    counts = [m[1] for m in a.meshes()]
+    assert counts == sorted(counts, reverse=True) and 20 <= a.num_meshes <= 25      # one mesh per material, sorted
+    v = a.vertices()
+    nrm = np.linalg.norm(v[:, :, 3:6], axis=2)
+    assert np.allclose(nrm, 1, atol=1e-3)
+    assert v[:, :, 6:].min() < 0 and v[:, :, 6:].max() > 1                          # UVs exercise the wrap loops
+    # the camera preset sits inside the court; the default-Sponza variant is 1/120 the size
+    lo, hi = v[:, :, :3].reshape(-1, 3).min(0), v[:, :, :3].reshape(-1, 3).max(0)
+    assert (lo <= [-1280, 0, -50]).all() and (hi > [-1280, 138, -50]).all()
+    s = host.HostScene.atrium(abi.SCENE_SPONZA, 5000, 0, 1)
+    sv = s.vertices()[:, :, :3].reshape(-1, 3)
+    assert sv.max() < 20 and sv.min() > -20
+    d = a.desc.contents
+    textured = [i for i in range(d.num_materials) if d.materials[i].tex_width == 32]
+    assert len(textured) >= 20 and all(d.materials[i].nml_width == 32 for i in textured)
+
+
+def test_instancing_multiplies_triangles():
+    base = host.HostScene.atrium(abi.SCENE_CRYTEK, 3000, 0, 1)
+    inst = base.instanced(4, 5000.0)
+    assert inst.num_triangles == 4 * base.num_triangles and inst.num_meshes == base.num_meshes
+    assert inst.vertices()[:, :, 0].max() > base.vertices()[:, :, 0].max() + 4000
+
+
+def test_output_stage_truncates_like_the_reference(tmp_path):
+    img = np.array([[0.0, 0.99, 1.0], [127.5, 254.999, 255.0]], dtype=np.float32)
+    packed = host.pack_bgra(img)
+    assert packed[0] == (0 | (0 << 8) | (1 << 16) | (255 << 24))           # CPUPathTracer.cpp:509: b | g<<8 | r<<16
+    assert packed[1] == (127 | (254 << 8) | (255 << 16) | (255 << 24))
+    path = tmp_path / "o.ppm"
+    host.write_ppm(str(path), img.reshape(1, 2, 3), 2, 1)
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n2 1\n255\n") and data[-6:] == bytes([1, 0, 0, 255, 254, 127])   # RGB order in the file
+
+
+def test_shard_fields_and_tile_owner():
+    assert sharding.shard_fields(0, 1, 128) == dict(shard_rank=0, shard_count=1, tile_size=32, sample_begin=0, sample_end=0)
+    f = [sharding.shard_fields(r, 4, 128, "tiles") for r in range(4)]
+    assert [x["shard_rank"] for x in f] == [0, 1, 2, 3] and all(x["shard_count"] == 4 for x in f)
+    g = [sharding.shard_fields(r, 3, 10, "samples") for r in range(3)]
+    assert [(x["sample_begin"], x["sample_end"]) for x in g] == [(0, 4), (4, 8), (8, 10)]
+    g = [sharding.shard_fields(r, 8, 4, "samples") for r in range(8)]
+    covered = sorted(n for x in g for n in range(x["sample_begin"], x["sample_end"]))
+    assert covered == [0, 1, 2, 3] and g[7]["sample_begin"] == g[7]["sample_end"] == 4
+    owners = {sharding.tile_owner(x, y, 100, 4, 32) for x in range(100) for y in range(70)}
+    assert owners == {0, 1, 2, 3}
+    assert sharding.tile_owner(31, 31, 100, 4, 32) == 0 and sharding.tile_owner(32, 0, 100, 4, 32) == 1
+    assert sharding.tile_owner(0, 32, 100, 4, 32) == 0                  # 4 tiles per row -> row 1 starts at tile 4
