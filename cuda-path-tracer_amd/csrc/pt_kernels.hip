@@ -15,6 +15,11 @@
 #include "pt_device.h"
 
 #define WAVE 64
+// rays a wave draws from a queue per atomic on the queue head: a single word takes only about
+// 90 returning atomics per microsecond on this machine, so one atomic must cover many rays
+#define TRACE_BATCH 8
+// queue entries a wave of a shading kernel handles per reservation in its output queues
+#define SHADE_ITEMS 16
 
 // ---------------------------------------------------------------------------------------
 // k_raygen: CPUPathTracer.cpp:489-497 (the CPU flavour transforms (vx,vy,1) first and
@@ -83,10 +88,11 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
     for (;;) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(head, WAVE);
+        if (lane == 0) base = atomicAdd(head, WAVE * TRACE_BATCH);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
-        int i = base + lane;
+      for (int sub = 0; sub < TRACE_BATCH; sub++) {
+        int i = base + sub * WAVE + lane;
         if (i < n) {
             float4 o4 = q.o[i], d4 = q.d[i];
             Hit h;
@@ -104,6 +110,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 flags[i] = found ? 1 : 0;
             }
         }
+      }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
     if (lane == 0 && rs) {
@@ -120,7 +127,7 @@ static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
     if (perCU > 32) perCU = 32;
     if (perCU < 1) perCU = 1;
     long long resident = (long long)numCUs * perCU;
-    long long needed = ((long long)maxCount + WAVE - 1) / WAVE;
+    long long needed = ((long long)maxCount + WAVE * TRACE_BATCH - 1) / (WAVE * TRACE_BATCH);
     long long g = needed < resident ? needed : resident;
     return (int)(g < 1 ? 1 : g);
 }
@@ -335,41 +342,60 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
                                                      int32_t* shadowCount, RayQueue nextQ, int32_t* nextCount)
 {
     const int n = *d_count;
-    const int stride = gridDim.x * blockDim.x;
-    // every wave runs the same number of rounds so that the wave-wide appends see all lanes
-    const int rounds = (n + stride - 1) / stride;
-    for (int r = 0; r < rounds; r++) {
-        int i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool inRange = i < n;
-        float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
-        int tri = __float_as_int(h.w);
-        bool isHit = inRange && tri >= 0;
-        int slot = 0;
-        F3 so = f3(0, 0, 0), sd = f3(0, 0, 0), no = f3(0, 0, 0), nd = f3(0, 0, 0);
-        bool spawn = isHit && (level < 3);     // a sample drawn at depth 3 is not traced (PathTracer.cu:380)
-        if (isHit) {
-            slot = __float_as_int(q.o[i].w);
-            Surface sf = surface_at(S, R, tri, h.y, h.z);
-            float D = direct_term(R, sf, so, sd);
-            pathState[(size_t)(level - 1) * slotsPerLevel + slot] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
-            if (spawn) {
-                int a = slot % nAct, s = slot / nAct;
-                uint32_t p = (uint32_t)actPix[a], smp = (uint32_t)(n0 + s);
-                float r1 = rng_u01(R.seed, p, smp, (uint32_t)level, 0), r2 = rng_u01(R.seed, p, smp, (uint32_t)level, 1);
-                nd = to_world(sample_hemisphere(r1, r2), sf.N, sf.Nt, sf.Nb);
-                no = f3add(sf.hp, f3scale(nd, PT_BIAS));
-            }
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wavesPerBlock = blockDim.x / WAVE;
+    const int64_t wave = (int64_t)blockIdx.x * wavesPerBlock + threadIdx.x / WAVE;
+    const int64_t numWaves = (int64_t)gridDim.x * wavesPerBlock;
+    const bool spawnLevel = level < 3;          // a sample drawn at depth 3 is not traced (PathTracer.cu:380)
+    // a wave owns SHADE_ITEMS * 64 consecutive queue entries at a time; it first counts its hits
+    // (one ballot per 64 entries) and reserves their places in the output queues with ONE atomic
+    // per queue, then shades and writes.  Both output queues receive the same entries in the same
+    // order, so one reservation index serves both.
+    for (int64_t first = wave * (SHADE_ITEMS * WAVE); first < n; first += numWaves * (SHADE_ITEMS * WAVE)) {
+        int total = 0;
+        #pragma unroll
+        for (int k = 0; k < SHADE_ITEMS; k++) {
+            int64_t i = first + k * WAVE + lane;
+            bool h = (i < n) && (__float_as_int(hit[i].w) >= 0);
+            total += __popcll(__ballot(h));
         }
-        int si = wave_append(isHit, shadowCount);
-        if (isHit) {
-            shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
-            shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
+        if (total == 0) continue;
+        int sbase = 0, nbase = 0;
+        if (lane == 0) {
+            sbase = atomicAdd(shadowCount, total);
+            if (spawnLevel) nbase = atomicAdd(nextCount, total);
         }
-        if (level < 3) {
-            int ni = wave_append(spawn, nextCount);
-            if (spawn) {
-                nextQ.o[ni] = make_float4(no.x, no.y, no.z, __int_as_float(slot));
-                nextQ.d[ni] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+        sbase = __builtin_amdgcn_readfirstlane(sbase);
+        nbase = __builtin_amdgcn_readfirstlane(nbase);
+        int running = 0;
+        for (int k = 0; k < SHADE_ITEMS; k++) {
+            int64_t i = first + k * WAVE + lane;
+            bool inRange = i < n;
+            float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
+            int tri = __float_as_int(h.w);
+            bool isHit = inRange && tri >= 0;
+            unsigned long long mask = __ballot(isHit);
+            if (mask == 0) continue;
+            int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            int idx = running + prefix;
+            running += __popcll(mask);
+            if (isHit) {
+                int slot = __float_as_int(q.o[i].w);
+                Surface sf = surface_at(S, R, tri, h.y, h.z);
+                F3 so, sd;
+                float D = direct_term(R, sf, so, sd);
+                pathState[(size_t)(level - 1) * slotsPerLevel + slot] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
+                shadowQ.o[sbase + idx] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
+                shadowQ.d[sbase + idx] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
+                if (spawnLevel) {
+                    int a = slot % nAct, s = slot / nAct;
+                    uint32_t p = (uint32_t)actPix[a], smp = (uint32_t)(n0 + s);
+                    float r1 = rng_u01(R.seed, p, smp, (uint32_t)level, 0), r2 = rng_u01(R.seed, p, smp, (uint32_t)level, 1);
+                    F3 nd = to_world(sample_hemisphere(r1, r2), sf.N, sf.Nt, sf.Nb);
+                    F3 no = f3add(sf.hp, f3scale(nd, PT_BIAS));
+                    nextQ.o[nbase + idx] = make_float4(no.x, no.y, no.z, __int_as_float(slot));
+                    nextQ.d[nbase + idx] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                }
             }
         }
     }
@@ -381,8 +407,9 @@ void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, cons
                          int32_t* d_shadowCount, RayQueue nextQ, int32_t* d_nextCount, hipStream_t s)
 {
     if (maxCount <= 0) return;
-    long long blocks = ((long long)maxCount + 255) / 256;
-    if (blocks > 256 * 64) blocks = 256 * 64;      // grid-stride beyond this
+    const int perBlock = (256 / WAVE) * SHADE_ITEMS * WAVE;
+    long long blocks = ((long long)maxCount + perBlock - 1) / perBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;      // waves stride over the queue beyond this
     hipLaunchKernelGGL(k_shade_bounce, dim3((unsigned)blocks), dim3(256), 0, s, S, R, q, hit, d_count, level, actPix, nAct, n0,
                        pathState, slotsPerLevel, shadowQ, d_shadowCount, nextQ, d_nextCount);
 }
