@@ -263,8 +263,21 @@ __device__ __forceinline__ uint32_t child_code(const BNode& c, int id)
     return c.state == NODE_LEAF ? (MIPT_LEAF_BIT | (uint32_t)c.start) : (uint32_t)id;
 }
 
-__global__ void __launch_bounds__(256) k_emit_nodes(const BNode* __restrict__ nodes, int32_t numNodes, float pad, float4* out,
-                                                   BuildCounters* ctr)
+struct QuantGrid { float qmin[3], invCell[3]; };
+
+__device__ __forceinline__ uint32_t quant_lo(float v, float qmin, float invCell)
+{
+    float q = floorf((v - qmin) * invCell);
+    return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f);
+}
+__device__ __forceinline__ uint32_t quant_hi(float v, float qmin, float invCell)
+{
+    float q = ceilf((v - qmin) * invCell);
+    return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f);
+}
+
+__global__ void __launch_bounds__(256) k_emit_nodes(const BNode* __restrict__ nodes, int32_t numNodes, float pad, QuantGrid G,
+                                                   uint4* out, BuildCounters* ctr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= numNodes) return;
@@ -272,24 +285,26 @@ __global__ void __launch_bounds__(256) k_emit_nodes(const BNode* __restrict__ no
     float mn[3] = { key2f(nd.bminI[0]), key2f(nd.bminI[1]), key2f(nd.bminI[2]) };
     float mx[3] = { key2f(nd.bmaxI[0]), key2f(nd.bmaxI[1]), key2f(nd.bmaxI[2]) };
     double area = (double)box_area(mn, mx);
-    float4* o = out + (size_t)i * 4;
+    uint4* o = out + (size_t)i * 2;
     if (nd.state != NODE_INNER) {
         atomicAdd(&ctr->sah, area * (double)nd.count);
-        o[0] = o[1] = o[2] = o[3] = make_float4(0, 0, 0, 0);
+        o[0] = o[1] = make_uint4(0, 0, 0, 0);
         return;
     }
     atomicAdd(&ctr->sah, area);
     const BNode& l = nodes[nd.left];
     const BNode& r = nodes[nd.left + 1];
-    // boxes grow by `pad` on every side: the box test is allowed to be generous, never tight
-    float l0 = key2f(l.bminI[0]) - pad, l1 = key2f(l.bminI[1]) - pad, l2 = key2f(l.bminI[2]) - pad;
-    float L0 = key2f(l.bmaxI[0]) + pad, L1 = key2f(l.bmaxI[1]) + pad, L2 = key2f(l.bmaxI[2]) + pad;
-    float r0 = key2f(r.bminI[0]) - pad, r1 = key2f(r.bminI[1]) - pad, r2 = key2f(r.bminI[2]) - pad;
-    float R0 = key2f(r.bmaxI[0]) + pad, R1 = key2f(r.bmaxI[1]) + pad, R2 = key2f(r.bmaxI[2]) + pad;
-    o[0] = make_float4(l0, l1, l2, L0);
-    o[1] = make_float4(L1, L2, r0, r1);
-    o[2] = make_float4(r2, R0, R1, R2);
-    o[3] = make_float4(__uint_as_float(child_code(l, nd.left)), __uint_as_float(child_code(r, nd.left + 1)), 0.0f, 0.0f);
+    // boxes grow by `pad` on every side and are then rounded outwards to the 16-bit grid: the box
+    // test is allowed to be generous, never tight
+    uint32_t q[12];
+    for (int a = 0; a < 3; a++) {
+        q[a] = quant_lo(key2f(l.bminI[a]) - pad, G.qmin[a], G.invCell[a]);
+        q[3 + a] = quant_hi(key2f(l.bmaxI[a]) + pad, G.qmin[a], G.invCell[a]);
+        q[6 + a] = quant_lo(key2f(r.bminI[a]) - pad, G.qmin[a], G.invCell[a]);
+        q[9 + a] = quant_hi(key2f(r.bmaxI[a]) + pad, G.qmin[a], G.invCell[a]);
+    }
+    o[0] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16));
+    o[1] = make_uint4(q[8] | (q[9] << 16), q[10] | (q[11] << 16), child_code(l, nd.left), child_code(r, nd.left + 1));
 }
 
 __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ attr, const int32_t* __restrict__ primIdx,
@@ -345,6 +360,7 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     int cur = 0, numActive = 0;
     const unsigned gridN = (unsigned)((n + 255) / 256);
     float sceneAbs = 0, pad = 0, ms = 0;
+    QuantGrid grid = {};
 
     HIPCHK(hipMalloc(&primMin, sizeof(float4) * (size_t)n));
     HIPCHK(hipMalloc(&primMax, sizeof(float4) * (size_t)n));
@@ -394,15 +410,23 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         }
         pad = sceneAbs * (1.0f / 32768.0f);
         if (!(pad > 0.0f)) pad = 1e-30f;
+        // the 16-bit grid spans the padded scene box; a flat axis still gets a positive cell
+        for (int a = 0; a < 3; a++) {
+            float lo = k2f(rootH.bminI[a]) - 2.0f * pad, hi = k2f(rootH.bmaxI[a]) + 2.0f * pad;
+            float cell = (hi - lo) / 65535.0f;
+            if (!(cell > 0.0f)) cell = pad;
+            out->qmin[a] = lo; out->qcell[a] = cell;
+            grid.qmin[a] = lo; grid.invCell[a] = 1.0f / cell;
+        }
     }
     out->numNodeSlots = h.nodeCount;
     out->numLeafSlots = n;
-    HIPCHK(hipMalloc(&out->nodes, sizeof(float4) * 4 * (size_t)out->numNodeSlots));
+    HIPCHK(hipMalloc(&out->nodes, sizeof(uint4) * 2 * (size_t)out->numNodeSlots));
     HIPCHK(hipMalloc(&out->triV0, sizeof(float4) * (size_t)n));
     HIPCHK(hipMalloc(&out->triE1, sizeof(float4) * (size_t)n));
     HIPCHK(hipMalloc(&out->triE2, sizeof(float4) * (size_t)n));
     HIPCHK(hipMemsetAsync(&ctr->sah, 0, sizeof(double), stream));
-    hipLaunchKernelGGL(k_emit_nodes, dim3((unsigned)((h.nodeCount + 255) / 256)), dim3(256), 0, stream, nodes, h.nodeCount, pad, out->nodes, ctr);
+    hipLaunchKernelGGL(k_emit_nodes, dim3((unsigned)((h.nodeCount + 255) / 256)), dim3(256), 0, stream, nodes, h.nodeCount, pad, grid, out->nodes, ctr);
     hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(256), 0, stream, d_attr, primIdx[cur], posNode[cur], nodes, n, out->triV0, out->triE1, out->triE2);
     HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));

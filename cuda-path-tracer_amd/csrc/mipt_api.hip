@@ -223,11 +223,12 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
 
     rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);
     if (rc) { mipt_scene_destroy(s); return fail(rc, "BVH build failed"); }
-    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 64 * (size_t)s->bvh.numNodeSlots + 48 * (size_t)s->bvh.numLeafSlots);
+    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 32 * (size_t)s->bvh.numNodeSlots + 48 * (size_t)s->bvh.numLeafSlots);
 
     DevScene& D = s->dev;
     D.nodes = s->bvh.nodes; D.triV0 = s->bvh.triV0; D.triE1 = s->bvh.triE1; D.triE2 = s->bvh.triE2;
     D.attr = s->attr; D.triMat = s->triMat; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
+    for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
     D.stackDepth = s->bvh.maxDepth + 2;
     D.numTris = (int32_t)n; D.numMats = s->numMats;
@@ -256,10 +257,17 @@ int mipt_scene_bvh_sizes(const mipt_scene* s, int64_t* nodeSlots, int64_t* leafS
     return MIPT_OK;
 }
 
-int mipt_scene_download_bvh(const mipt_scene* s, float* nodes, float* v0, float* e1, float* e2)
+int mipt_scene_bvh_grid(const mipt_scene* s, float* qmin, float* qcell)
+{
+    if (!s || !qmin || !qcell) return fail(MIPT_E_INVALID, "null argument");
+    for (int a = 0; a < 3; a++) { qmin[a] = s->bvh.qmin[a]; qcell[a] = s->bvh.qcell[a]; }
+    return MIPT_OK;
+}
+
+int mipt_scene_download_bvh(const mipt_scene* s, uint32_t* nodes, float* v0, float* e1, float* e2)
 {
     if (!s) return fail(MIPT_E_INVALID, "null scene");
-    if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 64 * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
+    if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 32 * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
     if (v0 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(v0, s->bvh.triV0, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
     if (e1 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e1, s->bvh.triE1, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
     if (e2 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e2, s->bvh.triE2, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));

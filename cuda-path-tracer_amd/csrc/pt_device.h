@@ -117,18 +117,20 @@ __device__ __forceinline__ bool ray_triangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, fl
 }
 
 // ---------------------------------------------------------------------------------------
-// Ray prepared for the box test: reciprocal direction and -origin/direction, so that a slab
-// distance is one fused multiply-add.  A zero direction component is replaced by 1e-30.
+// Ray prepared for the box test on the 16-bit grid: with box coordinate = qmin + q * qcell the
+// slab distance (coordinate - origin) / direction becomes q * (qcell / d) + (qmin - o) / d, one
+// fused multiply-add per plane.  A zero direction component is replaced by 1e-30.
 struct BoxRay { float ix, iy, iz, nx, ny, nz; };
 
-__device__ __forceinline__ BoxRay make_box_ray(F3 o, F3 d)
+__device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
 {
     BoxRay r;
     float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-    r.nx = -o.x * r.ix; r.ny = -o.y * r.iy; r.nz = -o.z * r.iz;
+    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    r.nx = (S.qmin[0] - o.x) * ix; r.ny = (S.qmin[1] - o.y) * iy; r.nz = (S.qmin[2] - o.z) * iz;
+    r.ix = ix * S.qcell[0]; r.iy = iy * S.qcell[1]; r.iz = iz * S.qcell[2];
     return r;
 }
 
@@ -146,68 +148,6 @@ __device__ __forceinline__ bool box_test(const BoxRay& r, float bminx, float bmi
 }
 
 struct Hit { float t, u, v; int32_t tri; };
-
-// Closest-hit (ANY = false) or any-hit (ANY = true) search.  stack points at this lane's
-// column of the wave's LDS stack; entry k lives at stack[k * 64].
-// Closest: the accepted triangle with the smallest t below FLT_MAX; equal t -> lowest
-// global triangle id (TraceRays, PathTracer.cu:244-288 / Trace, CPUPathTracer.cpp:251-285).
-// Any: true as soon as one triangle is accepted with t < FLT_MAX (the bHitOnly result).
-template <bool ANY>
-__device__ __forceinline__ bool traverse(const DevScene& S, F3 o, F3 d, float eps, uint32_t* stack,
-                                         Hit& hit, uint32_t& nodeCount, uint32_t& triCount)
-{
-    hit.t = FLT_MAX; hit.u = 0; hit.v = 0; hit.tri = -1;
-    uint32_t cur = S.rootCode;
-    if (cur == MIPT_NO_NODE) return false;
-    BoxRay br = make_box_ray(o, d);
-    float tcull = FLT_MAX;
-    int sp = 0;
-    const float4* __restrict__ nodes = S.nodes;
-    for (;;) {
-        while (!(cur & MIPT_LEAF_BIT)) {
-            const float4* n = nodes + (size_t)cur * 4;
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            nodeCount++;
-            float t0, t1;
-            bool h0 = box_test(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tcull, t0);
-            bool h1 = box_test(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tcull, t1);
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            if (h0 & h1) {
-                bool firstIs0 = t0 <= t1;
-                uint32_t nearC = firstIs0 ? c0 : c1, farC = firstIs0 ? c1 : c0;
-                stack[sp * 64] = farC;
-                sp = (sp + 1 < S.stackDepth) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
-                cur = nearC;
-            } else if (h0 | h1) {
-                cur = h0 ? c0 : c1;
-            } else {
-                if (sp == 0) return hit.tri >= 0;
-                sp--; cur = stack[sp * 64];
-            }
-        }
-        // leaf
-        uint32_t slot = cur & ~MIPT_LEAF_BIT;
-        uint32_t last;
-        do {
-            float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
-            triCount++;
-            float t, u, v;
-            if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
-                int32_t id = (int32_t)__float_as_uint(a.w);
-                if (ANY) {
-                    if (t < FLT_MAX) { hit.t = t; hit.tri = id; return true; }
-                } else if (t < hit.t || (t == hit.t && id < hit.tri)) {
-                    hit.t = t; hit.u = u; hit.v = v; hit.tri = id;
-                    tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
-                }
-            }
-            last = __float_as_uint(b.w);
-            slot++;
-        } while (!last && slot < (uint32_t)S.numTris);
-        if (sp == 0) return hit.tri >= 0;
-        sp--; cur = stack[sp * 64];
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // wave64 primitives

@@ -6,13 +6,14 @@
 
 // ---- device-side scene --------------------------------------------------------------
 //
-// BVH node slot (64 B = 4 x float4, fetched by one lane with four 16-byte loads from one
-// 64-byte-aligned record): the boxes of BOTH children live in the parent, so that one
-// fetch decides both descents.
-//   q0 = (c0min.x, c0min.y, c0min.z, c0max.x)
-//   q1 = (c0max.y, c0max.z, c1min.x, c1min.y)
-//   q2 = (c1min.z, c1max.x, c1max.y, c1max.z)
-//   q3 = (bits child0, bits child1, 0, 0)
+// BVH node slot (32 B = 2 x uint4, fetched by one lane with two 16-byte loads from one
+// 32-byte-aligned record): the boxes of BOTH children live in the parent, so that one fetch
+// decides both descents.  Box coordinates are 16-bit cells of a uniform grid over the scene
+// (coordinate = qmin + q * qcell, minima rounded down, maxima rounded up after padding): the
+// box test only has to be generous, never tight, and the traversal is limited by the number of
+// per-lane memory requests it issues, so a node must cost as few 16-byte requests as possible.
+//   u0 = (c0min.x | c0min.y << 16, c0min.z | c0max.x << 16, c0max.y | c0max.z << 16, c1min.x | c1min.y << 16)
+//   u1 = (c1min.z | c1max.x << 16, c1max.y | c1max.z << 16, child0, child1)
 // A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  Leaf slots are three
 // parallel float4 arrays in BVH order (the three loads of a lane hit three arrays, consecutive
 // slots of one leaf are consecutive in each):
@@ -36,7 +37,7 @@ struct DevMaterial {
 };
 
 struct DevScene {
-    const float4*      nodes;
+    const uint4*       nodes;
     const float4*      triV0;
     const float4*      triE1;
     const float4*      triE2;
@@ -45,6 +46,8 @@ struct DevScene {
     const DevMaterial* mats;
     const uint32_t*    texels;
     const float*       texelsF;
+    float              qmin[3];    // origin and cell size of the 16-bit grid the node boxes live on
+    float              qcell[3];
     uint32_t           rootCode;   // MIPT_NO_NODE for an empty scene
     int32_t            stackDepth; // entries of the per-lane traversal stack
     int32_t            numTris;
@@ -73,7 +76,8 @@ enum {
 
 // ---- BVH build result -------------------------------------------------------------------
 struct BvhResult {
-    float4*  nodes = nullptr;     // numNodeSlots * 4
+    uint4*   nodes = nullptr;     // numNodeSlots * 2
+    float    qmin[3] = { 0, 0, 0 }, qcell[3] = { 1, 1, 1 };
     float4*  triV0 = nullptr;
     float4*  triE1 = nullptr;
     float4*  triE2 = nullptr;

@@ -15,9 +15,6 @@
 #include "pt_device.h"
 
 #define WAVE 64
-// rays a wave draws from a queue per atomic on the queue head: a single word takes only about
-// 90 returning atomics per microsecond on this machine, so one atomic must cover many rays
-#define TRACE_BATCH 8
 // queue entries a wave of a shading kernel handles per reservation in its output queues
 #define SHADE_ITEMS 16
 
@@ -70,11 +67,23 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------------------
-// Traversal kernels.  One wave per workgroup; a wave draws 64 rays at a time from the queue
-// through one atomic on *head and leaves when the queue is drained, so the grid can be
-// sized to the machine and needs no host-side knowledge of the queue length.
-// MODE 0: closest hit -> hit[i]; MODE 1: any-hit, clears the direct term of the ray's slot
-// when occluded; MODE 2: any-hit -> flags[i].
+// Traversal kernels: TraceRays / Intersect of PathTracer.cu:193-288 over a queue of rays.
+//
+// One wave per workgroup, one ray per lane, per-lane stack in LDS (entry k of lane l at
+// stack[k * 64 + l]: every lane of a half-wave hits its own bank).  Waves are persistent: a wave
+// reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
+// as they fall idle; whenever fewer than TRACE_REFILL lanes are still traversing, the wave leaves
+// the traversal loop and refills the idle lanes, so a few long rays do not hold 64 lanes hostage.
+//
+// Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
+// lowest global triangle id; hit[i] = (t, ua, va, id or -1).
+// Any hit (MODE 1, 2): true as soon as one triangle is accepted with t < FLT_MAX (the bHitOnly
+// result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
+// to; MODE 2 writes flags[i].
+#define TRACE_CHUNK 1024
+#define TRACE_REFILL 40
+#define NODE_DONE 0xFFFFFFFEu
+
 template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
@@ -85,32 +94,127 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     const int lane = threadIdx.x;
     uint32_t* stack = smem + lane;
     const int n = *d_count;
+    const uint4* __restrict__ nodes = S.nodes;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+
+    int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
+    bool queueDry = false;
+    // per-lane traversal state
+    uint32_t cur = NODE_DONE;
+    int sp = 0, rayIdx = -1, tag0 = 0, tag1 = 0;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    BoxRay br = {};
+    float tcull = FLT_MAX;
+    Hit best; best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
+
     for (;;) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(head, WAVE * TRACE_BATCH);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-      for (int sub = 0; sub < TRACE_BATCH; sub++) {
-        int i = base + sub * WAVE + lane;
-        if (i < n) {
-            float4 o4 = q.o[i], d4 = q.d[i];
-            Hit h;
-            rayCount++;
-            bool found = traverse<MODE != 0>(S, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z), eps, stack, h, nodeCount, triCount);
-            if (MODE == 0) {
-                hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(found ? h.tri : -1));
-            } else if (MODE == 1) {
-                if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
-                    int slot = __float_as_int(o4.w), level = __float_as_int(d4.w);
-                    if (level == 0) pixState0[(size_t)slot * 4].x = 0.0f;
-                    else pathState[(size_t)(level - 1) * slotsPerLevel + slot].x = 0.0f;
+        // ---- hand rays to idle lanes
+        bool idle = (cur == NODE_DONE);
+        unsigned long long idleMask = __ballot(idle);
+        if (idleMask) {
+            if (rangeNext >= rangeEnd && !queueDry) {
+                int b = 0;
+                if (lane == 0) b = atomicAdd(head, TRACE_CHUNK);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= n) queueDry = true;
+                else { rangeNext = b; rangeEnd = (b + TRACE_CHUNK < n) ? b + TRACE_CHUNK : n; }
+            }
+            int avail = rangeEnd - rangeNext;
+            if (avail > 0) {
+                int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                if (idle && prefix < avail) {
+                    rayIdx = rangeNext + prefix;
+                    float4 o4 = q.o[rayIdx], d4 = q.d[rayIdx];
+                    o = f3(o4.x, o4.y, o4.z); d = f3(d4.x, d4.y, d4.z);
+                    tag0 = __float_as_int(o4.w); tag1 = __float_as_int(d4.w);
+                    br = make_box_ray(S, o, d);
+                    tcull = FLT_MAX;
+                    best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
+                    sp = 0;
+                    cur = S.rootCode;           // MIPT_NO_NODE (empty scene) is handled below as a finished ray
+                    rayCount++;
                 }
-            } else {
-                flags[i] = found ? 1 : 0;
+                int want = __popcll(idleMask);
+                rangeNext += (want < avail) ? want : avail;
             }
         }
-      }
+        if (__ballot(cur != NODE_DONE) == 0) {
+            if (queueDry && rangeNext >= rangeEnd) break;
+            continue;
+        }
+
+        // ---- traverse
+        while (cur != NODE_DONE) {
+            if (cur != MIPT_NO_NODE) {
+                // inner nodes: near child first, far child pushed
+                while (!(cur & MIPT_LEAF_BIT)) {
+                    const uint4* nd = nodes + (size_t)cur * 2;
+                    uint4 u0 = nd[0], u1 = nd[1];
+                    nodeCount++;
+                    float t0, t1;
+                    bool h0 = box_test(br, (float)(u0.x & 0xffffu), (float)(u0.x >> 16), (float)(u0.y & 0xffffu),
+                                       (float)(u0.y >> 16), (float)(u0.z & 0xffffu), (float)(u0.z >> 16), tcull, t0);
+                    bool h1 = box_test(br, (float)(u0.w & 0xffffu), (float)(u0.w >> 16), (float)(u1.x & 0xffffu),
+                                       (float)(u1.x >> 16), (float)(u1.y & 0xffffu), (float)(u1.y >> 16), tcull, t1);
+                    uint32_t c0 = u1.z, c1 = u1.w;
+                    if (h0 & h1) {
+                        bool firstIs0 = t0 <= t1;
+                        stack[sp * WAVE] = firstIs0 ? c1 : c0;
+                        sp = (sp + 1 < S.stackDepth) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
+                        cur = firstIs0 ? c0 : c1;
+                    } else if (h0 | h1) {
+                        cur = h0 ? c0 : c1;
+                    } else if (sp > 0) {
+                        sp--; cur = stack[sp * WAVE];
+                    } else {
+                        cur = NODE_DONE;
+                        break;
+                    }
+                }
+                // leaf: the exact triangle test on every triangle of the leaf
+                if (cur != NODE_DONE) {
+                    uint32_t slot = cur & ~MIPT_LEAF_BIT;
+                    uint32_t last;
+                    bool occluded = false;
+                    do {
+                        float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
+                        triCount++;
+                        float t, u, v;
+                        if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
+                            int32_t id = (int32_t)__float_as_uint(a.w);
+                            if (MODE != 0) {
+                                if (t < FLT_MAX) { best.t = t; best.tri = id; occluded = true; }
+                            } else if (t < best.t || (t == best.t && id < best.tri)) {
+                                best.t = t; best.u = u; best.v = v; best.tri = id;
+                                tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+                            }
+                        }
+                        last = __float_as_uint(b.w);
+                        slot++;
+                    } while (!last && !occluded && slot < (uint32_t)S.numTris);
+                    if (occluded || sp == 0) cur = NODE_DONE;
+                    else { sp--; cur = stack[sp * WAVE]; }
+                }
+            } else {
+                cur = NODE_DONE;
+            }
+            if (cur == NODE_DONE) {
+                // ray finished: write its result
+                bool found = best.tri >= 0;
+                if (MODE == 0) {
+                    hit[rayIdx] = make_float4(best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
+                } else if (MODE == 1) {
+                    if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
+                        if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
+                        else pathState[(size_t)(tag1 - 1) * slotsPerLevel + tag0].x = 0.0f;
+                    }
+                } else {
+                    flags[rayIdx] = found ? 1 : 0;
+                }
+            }
+            // too few lanes left in this loop: go and refill the idle ones
+            if (__popcll(__ballot(true)) < TRACE_REFILL && !(queueDry && rangeNext >= rangeEnd)) break;
+        }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
     if (lane == 0 && rs) {
@@ -127,7 +231,7 @@ static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
     if (perCU > 32) perCU = 32;
     if (perCU < 1) perCU = 1;
     long long resident = (long long)numCUs * perCU;
-    long long needed = ((long long)maxCount + WAVE * TRACE_BATCH - 1) / (WAVE * TRACE_BATCH);
+    long long needed = ((long long)maxCount + TRACE_CHUNK - 1) / TRACE_CHUNK;
     long long g = needed < resident ? needed : resident;
     return (int)(g < 1 ? 1 : g);
 }

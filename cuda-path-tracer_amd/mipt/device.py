@@ -33,6 +33,7 @@ def lib():
         L.mipt_scene_destroy.restype = None
         L.mipt_scene_get_info.argtypes = [vp, C.POINTER(abi.SceneInfo)]
         L.mipt_scene_bvh_sizes.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_uint32)]
+        L.mipt_scene_bvh_grid.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mipt_scene_download_bvh.argtypes = [vp, vp, vp, vp, vp]
         L.mipt_trace_rays.argtypes = [vp, vp, i64, f32, vp, vp, vp]
         L.mipt_frame_create.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.POINTER(vp)]
@@ -89,12 +90,15 @@ class Scene:
     def download_bvh(self):
         ns, ls, root = C.c_int64(), C.c_int64(), C.c_uint32()
         _check(lib().mipt_scene_bvh_sizes(self._h, C.byref(ns), C.byref(ls), C.byref(root)))
-        nodes = np.zeros((ns.value, 16), dtype=np.float32)
+        nodes = np.zeros((ns.value, 8), dtype=np.uint32)
         v0 = np.zeros((ls.value, 4), dtype=np.float32)
         e1 = np.zeros((ls.value, 4), dtype=np.float32)
         e2 = np.zeros((ls.value, 4), dtype=np.float32)
         _check(lib().mipt_scene_download_bvh(self._h, nodes.ctypes.data, v0.ctypes.data, e1.ctypes.data, e2.ctypes.data))
-        return nodes, v0, e1, e2, root.value
+        qmin, qcell = (C.c_float * 3)(), (C.c_float * 3)()
+        _check(lib().mipt_scene_bvh_grid(self._h, qmin, qcell))
+        grid = (np.array(qmin[:], dtype=np.float32), np.array(qcell[:], dtype=np.float32))
+        return nodes, v0, e1, e2, root.value, grid
 
     def trace_rays(self, rays, eps=1e-20, closest=True, anyhit=True):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)

@@ -12,7 +12,7 @@ LEAF = 0x80000000
 
 def validate_bvh(scene_host, dev_scene):
     info = dev_scene.info()
-    nodes, v0, e1, e2, root = dev_scene.download_bvh()
+    nodes, v0, e1, e2, root, (qmin, qcell) = dev_scene.download_bvh()
     verts = scene_host.vertices()[:, :, :3]
     n = scene_host.num_triangles
     assert info.num_triangles == n and v0.shape[0] == n
@@ -26,7 +26,9 @@ def validate_bvh(scene_host, dev_scene):
     assert set(np.unique(last)) <= {0, 1} and last[-1] == 1
     tri_lo = np.minimum(np.minimum(p0, p1), p2)
     tri_hi = np.maximum(np.maximum(p0, p1), p2)
-    codes = nodes[:, 12:14].copy().view(np.uint32)
+    codes = nodes[:, 6:8]
+    q = np.stack([nodes[:, :6] & 0xFFFF, nodes[:, :6] >> 16], axis=2).reshape(-1, 12).astype(np.float64)   # c0 min, c0 max, c1 min, c1 max
+    qmin, qcell = qmin.astype(np.float64), qcell.astype(np.float64)
     seen = np.zeros(n, dtype=bool)
     max_depth = 0
     leaves = 0
@@ -51,13 +53,13 @@ def validate_bvh(scene_host, dev_scene):
                 assert (tri_lo[sl] >= lo).all() and (tri_hi[sl] <= hi).all()
             continue
         inner += 1
-        nd = nodes[code]
-        boxes = [(nd[0:3], np.array([nd[3], nd[4], nd[5]])), (np.array([nd[6], nd[7], nd[8]]), nd[9:12])]
+        nd = q[code]
+        boxes = [(qmin + nd[0:3] * qcell, qmin + nd[3:6] * qcell), (qmin + nd[6:9] * qcell, qmin + nd[9:12] * qcell)]
         for k in range(2):
             clo, chi = boxes[k]
             assert (clo <= chi).all()
             if lo is not None:      # nested up to the padding both levels carry
-                assert (clo >= lo - 1e-6 * np.abs(lo) - 1e-30).all() and (chi <= hi + 1e-6 * np.abs(hi) + 1e-30).all()
+                assert (clo >= lo - 1.01 * qcell).all() and (chi <= hi + 1.01 * qcell).all()
             stack.append((int(codes[code, k]), depth + 1, clo, chi))
     assert seen.all(), "some leaf slot is unreachable from the root"
     assert max_depth == info.max_depth and leaves == info.num_leaves and inner == info.num_nodes
