@@ -33,7 +33,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet, packed fp32 FMA
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TRI_TEST = 51              # full Moeller-Trumbore from three vertices
 FLOP_PER_BOX_TEST = 22
-BYTES_PER_NODE = 64                 # one node record = the boxes of both children + links
+BYTES_PER_NODE = 32                 # one node record = the 16-bit boxes of both children + links
 BYTES_PER_TRI_TEST = 36             # three float3 positions
 
 

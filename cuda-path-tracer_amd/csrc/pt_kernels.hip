@@ -13,6 +13,7 @@
 //   k_finalize        first-level sum, clamp, *255           PathTracer.cu:453-462, 550-552
 // A path slot is (first-bounce sample s of this pass, active pixel a): slot = s * nAct + a.
 #include "pt_device.h"
+#include <stdlib.h>
 
 #define WAVE 64
 // queue entries a wave of a shading kernel handles per reservation in its output queues
@@ -72,8 +73,14 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // One wave per workgroup, one ray per lane, per-lane stack in LDS (entry k of lane l at
 // stack[k * 64 + l]: every lane of a half-wave hits its own bank).  Waves are persistent: a wave
 // reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
-// as they fall idle; whenever fewer than TRACE_REFILL lanes are still traversing, the wave leaves
-// the traversal loop and refills the idle lanes, so a few long rays do not hold 64 lanes hostage.
+// as soon as they fall idle.
+//
+// Every lane is in one of three states: at an inner node, at a triangle of a leaf, or idle.  One
+// loop iteration is ONE kind of step for the whole wave, chosen by vote: a triangle step when at
+// least `triVote` lanes wait at a triangle (or no lane is at an inner node), otherwise a node
+// step.  Lanes of the other kind sit the iteration out.  This replaces the usual "descend until
+// every lane has found a leaf" loop, in which a 64-wide wave spends most of its time waiting for
+// its slowest lane.
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
@@ -81,26 +88,28 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 1024
-#define TRACE_REFILL 40
-#define NODE_DONE 0xFFFFFFFEu
+#define TRACE_TRI_VOTE 24
+#define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
+#define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
 
 template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats)
+                                               float eps, unsigned long long* stats, int triVote)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
     uint32_t* stack = smem + lane;
     const int n = *d_count;
     const uint4* __restrict__ nodes = S.nodes;
+    const int stackTop = S.stackDepth - 1;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
 
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
     bool queueDry = false;
     // per-lane traversal state
-    uint32_t cur = NODE_DONE;
+    uint32_t cur = LANE_IDLE;
     int sp = 0, rayIdx = -1, tag0 = 0, tag1 = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     BoxRay br = {};
@@ -109,10 +118,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
 
     for (;;) {
         // ---- hand rays to idle lanes
-        bool idle = (cur == NODE_DONE);
-        unsigned long long idleMask = __ballot(idle);
-        if (idleMask) {
-            if (rangeNext >= rangeEnd && !queueDry) {
+        unsigned long long idleMask = __ballot(cur == LANE_IDLE);
+        if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
+            if (rangeNext >= rangeEnd) {
                 int b = 0;
                 if (lane == 0) b = atomicAdd(head, TRACE_CHUNK);
                 b = __builtin_amdgcn_readfirstlane(b);
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
             int avail = rangeEnd - rangeNext;
             if (avail > 0) {
                 int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-                if (idle && prefix < avail) {
+                if (cur == LANE_IDLE && prefix < avail) {
                     rayIdx = rangeNext + prefix;
                     float4 o4 = q.o[rayIdx], d4 = q.d[rayIdx];
                     o = f3(o4.x, o4.y, o4.z); d = f3(d4.x, d4.y, d4.z);
@@ -131,23 +139,47 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     tcull = FLT_MAX;
                     best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
                     sp = 0;
-                    cur = S.rootCode;           // MIPT_NO_NODE (empty scene) is handled below as a finished ray
                     rayCount++;
+                    cur = (S.rootCode == MIPT_NO_NODE) ? LANE_FINISHED : S.rootCode;   // empty scene: every ray misses
                 }
                 int want = __popcll(idleMask);
                 rangeNext += (want < avail) ? want : avail;
             }
         }
-        if (__ballot(cur != NODE_DONE) == 0) {
+        const unsigned long long triMask = __ballot((int32_t)cur < 0), nodeMask = __ballot(cur < LANE_FINISHED);
+        if ((triMask | nodeMask) == 0 && __ballot(cur == LANE_FINISHED) == 0) {
             if (queueDry && rangeNext >= rangeEnd) break;
             continue;
         }
-
-        // ---- traverse
-        while (cur != NODE_DONE) {
-            if (cur != MIPT_NO_NODE) {
-                // inner nodes: near child first, far child pushed
-                while (!(cur & MIPT_LEAF_BIT)) {
+        if (nodeMask == 0 || __popcll(triMask) >= triVote) {
+            // ---- triangle step: the exact triangle test on one triangle of the lane's leaf
+            if ((int32_t)cur < 0) {
+                uint32_t slot = cur & ~MIPT_LEAF_BIT;
+                float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
+                triCount++;
+                float t, u, v;
+                bool occluded = false;
+                if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
+                    int32_t id = (int32_t)__float_as_uint(a.w);
+                    if (MODE != 0) {
+                        if (t < FLT_MAX) { best.t = t; best.tri = id; occluded = true; }
+                    } else if (t < best.t || (t == best.t && id < best.tri)) {
+                        best.t = t; best.u = u; best.v = v; best.tri = id;
+                        tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+                    }
+                }
+                bool last = __float_as_uint(b.w) != 0 || slot + 1 >= (uint32_t)S.numTris;
+                if (occluded) { cur = LANE_FINISHED; }
+                else if (!last) { cur = cur + 1; }
+                else if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+                else { cur = LANE_FINISHED; }
+            }
+        } else {
+            // ---- node steps, in a tight loop, until `triVote` lanes have left for a leaf or finished
+            int stay = __popcll(nodeMask) - triVote;
+            if (stay < 0) stay = 0;
+            do {
+                if (cur < LANE_FINISHED) {
                     const uint4* nd = nodes + (size_t)cur * 2;
                     uint4 u0 = nd[0], u1 = nd[1];
                     nodeCount++;
@@ -157,63 +189,34 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     bool h1 = box_test(br, (float)(u0.w & 0xffffu), (float)(u0.w >> 16), (float)(u1.x & 0xffffu),
                                        (float)(u1.x >> 16), (float)(u1.y & 0xffffu), (float)(u1.y >> 16), tcull, t1);
                     uint32_t c0 = u1.z, c1 = u1.w;
-                    if (h0 & h1) {
+                    if (h0 & h1) {                  // near child first, far child pushed
                         bool firstIs0 = t0 <= t1;
                         stack[sp * WAVE] = firstIs0 ? c1 : c0;
-                        sp = (sp + 1 < S.stackDepth) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
+                        sp = (sp < stackTop) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
                         cur = firstIs0 ? c0 : c1;
                     } else if (h0 | h1) {
                         cur = h0 ? c0 : c1;
                     } else if (sp > 0) {
                         sp--; cur = stack[sp * WAVE];
                     } else {
-                        cur = NODE_DONE;
-                        break;
+                        cur = LANE_FINISHED;
                     }
                 }
-                // leaf: the exact triangle test on every triangle of the leaf
-                if (cur != NODE_DONE) {
-                    uint32_t slot = cur & ~MIPT_LEAF_BIT;
-                    uint32_t last;
-                    bool occluded = false;
-                    do {
-                        float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
-                        triCount++;
-                        float t, u, v;
-                        if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
-                            int32_t id = (int32_t)__float_as_uint(a.w);
-                            if (MODE != 0) {
-                                if (t < FLT_MAX) { best.t = t; best.tri = id; occluded = true; }
-                            } else if (t < best.t || (t == best.t && id < best.tri)) {
-                                best.t = t; best.u = u; best.v = v; best.tri = id;
-                                tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
-                            }
-                        }
-                        last = __float_as_uint(b.w);
-                        slot++;
-                    } while (!last && !occluded && slot < (uint32_t)S.numTris);
-                    if (occluded || sp == 0) cur = NODE_DONE;
-                    else { sp--; cur = stack[sp * WAVE]; }
+            } while (__popcll(__ballot(cur < LANE_FINISHED)) > stay);
+        }
+        if (cur == LANE_FINISHED) {
+            bool found = best.tri >= 0;
+            if (MODE == 0) {
+                hit[rayIdx] = make_float4(best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
+            } else if (MODE == 1) {
+                if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
+                    if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
+                    else pathState[(size_t)(tag1 - 1) * slotsPerLevel + tag0].x = 0.0f;
                 }
             } else {
-                cur = NODE_DONE;
+                flags[rayIdx] = found ? 1 : 0;
             }
-            if (cur == NODE_DONE) {
-                // ray finished: write its result
-                bool found = best.tri >= 0;
-                if (MODE == 0) {
-                    hit[rayIdx] = make_float4(best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
-                } else if (MODE == 1) {
-                    if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
-                        if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
-                        else pathState[(size_t)(tag1 - 1) * slotsPerLevel + tag0].x = 0.0f;
-                    }
-                } else {
-                    flags[rayIdx] = found ? 1 : 0;
-                }
-            }
-            // too few lanes left in this loop: go and refill the idle ones
-            if (__popcll(__ballot(true)) < TRACE_REFILL && !(queueDry && rangeNext >= rangeEnd)) break;
+            cur = LANE_IDLE;
         }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
@@ -222,6 +225,20 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_NODES : ST_SHADOW_NODES], ns);
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_TRIS : ST_SHADOW_TRIS], ts);
     }
+}
+
+static int trace_tri_vote()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MIPT_TRACE_TRI_VOTE"); v = e ? atoi(e) : TRACE_TRI_VOTE; }
+    return v;
+}
+
+static size_t trace_smem(const DevScene& S)
+{
+    static int extra = -1;      // MIPT_TRACE_LDS_EXTRA: additional bytes per wave, to study occupancy
+    if (extra < 0) { const char* e = getenv("MIPT_TRACE_LDS_EXTRA"); extra = e ? atoi(e) : 0; }
+    return (size_t)S.stackDepth * WAVE * sizeof(uint32_t) + (size_t)extra;
 }
 
 static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
@@ -239,24 +256,24 @@ static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
-    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats);
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote());
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
                    unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
-    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats);
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote());
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
-    size_t smem = (size_t)S.stackDepth * WAVE * sizeof(uint32_t);
+    size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats);
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote());
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,20 @@
+"""Derived figures for the traversal and shading kernels from a pmc_passes.sh output directory."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    if any(k in r["kernel"] for k in ("k_trace", "shade_bounce")):
+        f = lambda k: float(r[k]) if r.get(k) else 0.0
+        cyc = f("GRBM_GUI_ACTIVE") / 8
+        wc = f("SQ_WAVE_CYCLES")
+        print("==", r["kernel"], "calls", r["calls"], "total_us", r["total_us"])
+        print("  active lanes per VALU instr      %.1f of 64" % (f("SQ_THREAD_CYCLES_VALU") / max(f("SQ_ACTIVE_INST_VALU"), 1)))
+        print("  wave instrs: VALU %.3g SALU %.3g VMEM_RD %.3g LDS %.3g" % (f("SQ_INSTS_VALU"), f("SQ_INSTS_SALU"), f("SQ_INSTS_VMEM_RD"), f("SQ_INSTS_LDS")))
+        print("  wave time: waiting %.2f, issue-stalled %.2f, issuing %.2f" % (f("SQ_WAIT_ANY") / wc, f("SQ_WAIT_INST_ANY") / wc, f("SQ_ACTIVE_INST_ANY") / wc))
+        print("  resident waves per SIMD          %.2f" % (4 * wc / cyc / 1024))
+        print("  VALU pipe busy (4 cyc per wave64 op) %.2f" % (f("SQ_INSTS_VALU") * 4 / 1024 / cyc))
+        print("  TA busy                          %.2f" % (f("TA_BUSY_avr") / cyc))
+        print("  L1 accesses %.3g, L1->L2 %.3g (L1 hit %.2f), L2 hit %.2f, fabric reads %.3g, FETCH_SIZE %.1f GB, WRITE_SIZE %.2f GB" % (
+            f("TCP_TOTAL_CACHE_ACCESSES_sum"), f("TCP_TCC_READ_REQ_sum"), 1 - f("TCP_TCC_READ_REQ_sum") / max(f("TCP_TOTAL_CACHE_ACCESSES_sum"), 1),
+            f("TCC_HIT_sum") / max(f("TCC_REQ_sum"), 1), f("TCC_EA0_RDREQ_sum"), f("FETCH_SIZE") / 1e6, f("WRITE_SIZE") / 1e6))

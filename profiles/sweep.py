@@ -1,0 +1,34 @@
+"""Runs bench.py once per value of an environment variable and prints one line per value.
+
+    python profiles/sweep.py MIPT_TRACE_REFILL 0 16 32 48 -- --steps 2 --warmup 1
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    args = sys.argv[1:]
+    extra = []
+    if "--" in args:
+        i = args.index("--")
+        args, extra = args[:i], args[i + 1:]
+    var, values = args[0], args[1:]
+    for v in values:
+        env = dict(os.environ, **{var: v})
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=env,
+                           capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            print(var, v, "FAILED", p.stderr[-400:])
+            break
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        r = d["roofline"]
+        print(f"{var}={v}: {d['value']:.0f} Mrays/s, {d['ms_per_step']:.1f} ms/frame, closest {r['avg_launch_ms']:.3f} ms/launch, "
+              f"share closest {r['kernel_time_share']['closest']:.3f} shadow {r['kernel_time_share']['shadow']:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
