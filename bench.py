@@ -93,7 +93,9 @@ def main():
     kind = {"crytek": abi.SCENE_CRYTEK, "sponza": abi.SCENE_SPONZA}[kind_name]
     scene = host.HostScene.atrium(kind, tris, tex, 1)
     cam, sun = host.camera_preset(kind, width, height, div)
-    dev = device.Scene(scene.desc)
+    dev = device.Scene(scene.desc, sah_bins=int(os.environ.get("MIPT_BENCH_BINS", "0")),
+                       max_leaf_triangles=int(os.environ.get("MIPT_BENCH_LEAF", "0")),
+                       traversal_cost=float(os.environ.get("MIPT_BENCH_TCOST", "0")))
     info = dev.info()
 
     shard = sharding.shard_fields(rank, world, samples, args.shard)

@@ -374,8 +374,9 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
     if (rc) { delete f; return rc; }
     const int64_t P = f->P;
     const int32_t ns = f->R.numSamples;
-    // samples per pass: about 16M path slots unless the caller fixes it
-    int32_t chunk = p->chunk_samples > 0 ? p->chunk_samples : (int32_t)((16ll << 20) / (P > 0 ? P : 1));
+    // samples per pass: up to 128M path slots (160 bytes each) unless the caller fixes it; long
+    // passes keep the machine full, every launch pays a tail while its last waves drain
+    int32_t chunk = p->chunk_samples > 0 ? p->chunk_samples : (int32_t)((128ll << 20) / (P > 0 ? P : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > ns) chunk = ns;
     if ((int64_t)chunk * P >= (1ll << 31) - 256) chunk = (int32_t)(((1ll << 31) - 256) / P);

@@ -87,7 +87,7 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // Any hit (MODE 1, 2): true as soon as one triangle is accepted with t < FLT_MAX (the bHitOnly
 // result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
 // to; MODE 2 writes flags[i].
-#define TRACE_CHUNK 1024
+#define TRACE_CHUNK 256
 #define TRACE_TRI_VOTE 24
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
 #define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
@@ -96,7 +96,7 @@ template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats, int triVote)
+                                               float eps, unsigned long long* stats, int triVote, int chunk)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
@@ -122,10 +122,10 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
             if (rangeNext >= rangeEnd) {
                 int b = 0;
-                if (lane == 0) b = atomicAdd(head, TRACE_CHUNK);
+                if (lane == 0) b = atomicAdd(head, chunk);
                 b = __builtin_amdgcn_readfirstlane(b);
                 if (b >= n) queueDry = true;
-                else { rangeNext = b; rangeEnd = (b + TRACE_CHUNK < n) ? b + TRACE_CHUNK : n; }
+                else { rangeNext = b; rangeEnd = (b + chunk < n) ? b + chunk : n; }
             }
             int avail = rangeEnd - rangeNext;
             if (avail > 0) {
@@ -234,6 +234,13 @@ static int trace_tri_vote()
     return v;
 }
 
+static int trace_chunk()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MIPT_TRACE_CHUNK"); v = e ? atoi(e) : TRACE_CHUNK; if (v < 64) v = 64; }
+    return v;
+}
+
 static size_t trace_smem(const DevScene& S)
 {
     static int extra = -1;      // MIPT_TRACE_LDS_EXTRA: additional bytes per wave, to study occupancy
@@ -248,7 +255,7 @@ static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
     if (perCU > 32) perCU = 32;
     if (perCU < 1) perCU = 1;
     long long resident = (long long)numCUs * perCU;
-    long long needed = ((long long)maxCount + TRACE_CHUNK - 1) / TRACE_CHUNK;
+    long long needed = ((long long)maxCount + trace_chunk() - 1) / trace_chunk();
     long long g = needed < resident ? needed : resident;
     return (int)(g < 1 ? 1 : g);
 }
@@ -258,7 +265,7 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote());
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk());
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
@@ -266,14 +273,14 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote());
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk());
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote());
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk());
 }
 
 // ---------------------------------------------------------------------------------------
