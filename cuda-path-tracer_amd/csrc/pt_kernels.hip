@@ -75,12 +75,13 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
 // as soon as they fall idle.
 //
-// Every lane is in one of three states: at an inner node, at a triangle of a leaf, or idle.  One
-// loop iteration is ONE kind of step for the whole wave, chosen by vote: a triangle step when at
-// least `triVote` lanes wait at a triangle (or no lane is at an inner node), otherwise a node
-// step.  Lanes of the other kind sit the iteration out.  This replaces the usual "descend until
-// every lane has found a leaf" loop, in which a 64-wide wave spends most of its time waiting for
-// its slowest lane.
+// Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  A loop iteration is
+// either ONE triangle step for the lanes that wait at a triangle (taken when `triVote` lanes wait
+// there or no lane is at an inner node), or a tight loop of node steps that runs until `nodeDrop`
+// of the lanes that entered it have left for a leaf or finished.  Lanes of the other kind sit the
+// phase out.  Both thresholds were chosen by measurement (profiles/): the kernel is limited by
+// the rate at which the memory pipeline accepts per-lane requests, not by vector issue, so long
+// node phases at falling lane occupancy cost less than frequent phase changes.
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
@@ -88,7 +89,8 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
-#define TRACE_TRI_VOTE 24
+#define TRACE_TRI_VOTE 16
+#define TRACE_NODE_DROP 48
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
 #define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
 
@@ -96,7 +98,7 @@ template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats, int triVote, int chunk)
+                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
@@ -175,8 +177,8 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 else { cur = LANE_FINISHED; }
             }
         } else {
-            // ---- node steps, in a tight loop, until `triVote` lanes have left for a leaf or finished
-            int stay = __popcll(nodeMask) - triVote;
+            // ---- node steps, in a tight loop, until `triVote` lanes wait at a leaf or have finished
+            int stay = __popcll(nodeMask) - nodeDrop;
             if (stay < 0) stay = 0;
             do {
                 if (cur < LANE_FINISHED) {
@@ -234,6 +236,13 @@ static int trace_tri_vote()
     return v;
 }
 
+static int trace_node_drop()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MIPT_TRACE_NODE_DROP"); v = e ? atoi(e) : TRACE_NODE_DROP; }
+    return v;
+}
+
 static int trace_chunk()
 {
     static int v = -1;
@@ -265,7 +274,7 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk());
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
@@ -273,14 +282,14 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk());
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk());
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
 }
 
 // ---------------------------------------------------------------------------------------
