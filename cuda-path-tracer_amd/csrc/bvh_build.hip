@@ -16,6 +16,9 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <chrono>
+#include <vector>
 
 #define MAX_BINS 32
 #define MAX_BUILD_DEPTH 60
@@ -303,8 +306,9 @@ __global__ void __launch_bounds__(256) k_emit_nodes(const BNode* __restrict__ no
         q[6 + a] = quant_lo(key2f(r.bminI[a]) - pad, G.qmin[a], G.invCell[a]);
         q[9 + a] = quant_hi(key2f(r.bmaxI[a]) + pad, G.qmin[a], G.invCell[a]);
     }
-    o[0] = make_uint4(q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16));
-    o[1] = make_uint4(q[8] | (q[9] << 16), q[10] | (q[11] << 16), child_code(l, nd.left), child_code(r, nd.left + 1));
+    // one word per child and axis: min | max << 16
+    o[0] = make_uint4(q[0] | (q[3] << 16), q[1] | (q[4] << 16), q[2] | (q[5] << 16), q[6] | (q[9] << 16));
+    o[1] = make_uint4(q[7] | (q[10] << 16), q[8] | (q[11] << 16), child_code(l, nd.left), child_code(r, nd.left + 1));
 }
 
 __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ attr, const int32_t* __restrict__ primIdx,
@@ -325,6 +329,51 @@ __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ at
 
 // ---------------------------------------------------------------------------------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "bvh build: %s failed: %s\n", #x, hipGetErrorString(e_)); rc = MIPT_E_DEVICE; goto done; } } while (0)
+
+// Rewrites the node array in cache-line groups: four 32-byte slots share one 128-byte line, and a
+// line holds a node together with the first inner descendants reached from it (breadth first), so
+// that the step from a node to its child usually stays inside the line that is already in the
+// vector cache.  Leaves own no slot, so the array also shrinks to the inner nodes.
+static int relayout_nodes(BvhResult* out, hipStream_t stream)
+{
+    const int64_t oldSlots = out->numNodeSlots;
+    if (oldSlots <= 0 || (out->rootCode & MIPT_LEAF_BIT)) return MIPT_OK;
+    std::vector<uint32_t> src((size_t)oldSlots * 8);
+    if (hipMemcpyAsync(src.data(), out->nodes, src.size() * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIPT_E_DEVICE;
+    if (hipStreamSynchronize(stream) != hipSuccess) return MIPT_E_DEVICE;
+    std::vector<uint32_t> newIdx((size_t)oldSlots, MIPT_NO_NODE), order;   // order[new] = old
+    order.reserve((size_t)oldSlots);
+    std::vector<uint32_t> roots{ 0u }, group;
+    size_t head = 0;
+    while (head < roots.size()) {
+        group.clear(); group.push_back(roots[head++]);
+        for (size_t g = 0; g < group.size(); g++) {
+            for (int c = 0; c < 2; c++) {
+                uint32_t code = src[(size_t)group[g] * 8 + 6 + c];
+                if (code & MIPT_LEAF_BIT) continue;
+                if (group.size() < 4) group.push_back(code); else roots.push_back(code);
+            }
+        }
+        for (uint32_t o : group) { newIdx[o] = (uint32_t)order.size(); order.push_back(o); }
+        while (order.size() % 4) order.push_back(MIPT_NO_NODE);
+    }
+    std::vector<uint32_t> dst(order.size() * 8, 0u);
+    for (size_t i = 0; i < order.size(); i++) {
+        if (order[i] == MIPT_NO_NODE) continue;
+        memcpy(&dst[i * 8], &src[(size_t)order[i] * 8], 32);
+        for (int c = 0; c < 2; c++) {
+            uint32_t code = dst[i * 8 + 6 + c];
+            if (!(code & MIPT_LEAF_BIT)) dst[i * 8 + 6 + c] = newIdx[code];
+        }
+    }
+    uint4* nn = nullptr;
+    if (hipMalloc(&nn, dst.size() * 4) != hipSuccess) return MIPT_E_DEVICE;
+    if (hipMemcpy(nn, dst.data(), dst.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(nn); return MIPT_E_DEVICE; }
+    (void)hipFree(out->nodes);
+    out->nodes = nn;
+    out->numNodeSlots = (int64_t)order.size();
+    return MIPT_OK;
+}
 
 void mipt_free_bvh(BvhResult* r)
 {
@@ -442,6 +491,15 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         float dx = k2f(rootH.bmaxI[0]) - k2f(rootH.bminI[0]), dy = k2f(rootH.bmaxI[1]) - k2f(rootH.bminI[1]), dz = k2f(rootH.bmaxI[2]) - k2f(rootH.bminI[2]);
         double ra = 2.0 * ((double)dx * dy + (double)dy * dz + (double)dz * dx);
         out->sahCost = ra > 0 ? h.sah / ra : 0.0;
+    }
+    {
+        const char* lay = getenv("MIPT_BVH_LAYOUT");
+        if (!lay || atoi(lay) != 0) {          // MIPT_BVH_LAYOUT=0 keeps the builder's breadth-first order (for comparison)
+            auto t0 = std::chrono::steady_clock::now();
+            rc = relayout_nodes(out, stream);
+            if (rc) goto done;
+            out->buildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
     }
 done:
     if (primMin) (void)hipFree(primMin);

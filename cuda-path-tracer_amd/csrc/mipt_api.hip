@@ -512,6 +512,10 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         unsigned long long h[ST_COUNT];
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS];
+#ifdef MIPT_TRACE_PROFILE
+        fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu\n",
+                h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6]);
+#endif
         stats->node_visits = h[ST_CLOSEST_NODES] + h[ST_SHADOW_NODES];
         stats->triangle_tests = h[ST_CLOSEST_TRIS] + h[ST_SHADOW_TRIS];
         stats->closest_node_visits = h[ST_CLOSEST_NODES]; stats->closest_triangle_tests = h[ST_CLOSEST_TRIS];

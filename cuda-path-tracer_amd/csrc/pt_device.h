@@ -120,7 +120,11 @@ __device__ __forceinline__ bool ray_triangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, fl
 // Ray prepared for the box test on the 16-bit grid: with box coordinate = qmin + q * qcell the
 // slab distance (coordinate - origin) / direction becomes q * (qcell / d) + (qmin - o) / d, one
 // fused multiply-add per plane.  A zero direction component is replaced by 1e-30.
-struct BoxRay { float ix, iy, iz, nx, ny, nz; };
+// Ray in the units of the node grid: a plane at grid coordinate q is crossed at t = q * i + n.
+// s is 16 on an axis where the direction is negative and 0 elsewhere: a node word holds
+// (min | max << 16) of one axis, and rotating it by s puts the plane the ray meets first into the
+// low half.
+struct BoxRay { float ix, iy, iz, nx, ny, nz; uint32_t sx, sy, sz; };
 
 __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
 {
@@ -128,21 +132,24 @@ __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
     float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-    float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    // one-ulp reciprocals: the boxes carry a margin of 2^-15 of the scene size
+    float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     r.nx = (S.qmin[0] - o.x) * ix; r.ny = (S.qmin[1] - o.y) * iy; r.nz = (S.qmin[2] - o.z) * iz;
     r.ix = ix * S.qcell[0]; r.iy = iy * S.qcell[1]; r.iz = iz * S.qcell[2];
+    r.sx = (__float_as_uint(dx) >> 31) << 4; r.sy = (__float_as_uint(dy) >> 31) << 4; r.sz = (__float_as_uint(dz) >> 31) << 4;
     return r;
 }
 
-// entry distance of the ray into the box, or a value > exit distance on a miss
-__device__ __forceinline__ bool box_test(const BoxRay& r, float bminx, float bminy, float bminz, float bmaxx,
-                                         float bmaxy, float bmaxz, float tcull, float& tnear)
+// Slab test against a box given as three node words; tnear = entry distance.  Conservative by
+// construction of the node boxes, never exact.
+__device__ __forceinline__ bool box_test(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, float& tnear)
 {
-    float x0 = __builtin_fmaf(bminx, r.ix, r.nx), x1 = __builtin_fmaf(bmaxx, r.ix, r.nx);
-    float y0 = __builtin_fmaf(bminy, r.iy, r.ny), y1 = __builtin_fmaf(bmaxy, r.iy, r.ny);
-    float z0 = __builtin_fmaf(bminz, r.iz, r.nz), z1 = __builtin_fmaf(bmaxz, r.iz, r.nz);
-    float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
+    uint32_t px = __builtin_amdgcn_alignbit(wx, wx, r.sx), py = __builtin_amdgcn_alignbit(wy, wy, r.sy), pz = __builtin_amdgcn_alignbit(wz, wz, r.sz);
+    float x0 = __builtin_fmaf((float)(px & 0xffffu), r.ix, r.nx), x1 = __builtin_fmaf((float)(px >> 16), r.ix, r.nx);
+    float y0 = __builtin_fmaf((float)(py & 0xffffu), r.iy, r.ny), y1 = __builtin_fmaf((float)(py >> 16), r.iy, r.ny);
+    float z0 = __builtin_fmaf((float)(pz & 0xffffu), r.iz, r.nz), z1 = __builtin_fmaf((float)(pz >> 16), r.iz, r.nz);
+    float tmin = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
+    float tmax = fminf(fminf(x1, y1), fminf(z1, tcull));
     tnear = tmin;
     return tmin <= tmax;
 }

@@ -71,7 +71,8 @@ struct DevRender {
 // ---- statistics slots (uint64 each) ---------------------------------------------------
 enum {
     ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
-    ST_COUNT = 8
+    ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel, 8 entries
+    ST_COUNT = 16
 };
 
 // ---- BVH build result -------------------------------------------------------------------

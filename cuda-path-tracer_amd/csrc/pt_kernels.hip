@@ -107,6 +107,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     const uint4* __restrict__ nodes = S.nodes;
     const int stackTop = S.stackDepth - 1;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+#ifdef MIPT_TRACE_PROFILE
+    uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0;
+#endif
 
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
     bool queueDry = false;
@@ -119,6 +122,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     Hit best; best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
 
     for (;;) {
+#ifdef MIPT_TRACE_PROFILE
+        pOuter++;
+#endif
         // ---- hand rays to idle lanes
         unsigned long long idleMask = __ballot(cur == LANE_IDLE);
         if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
@@ -131,6 +137,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
             }
             int avail = rangeEnd - rangeNext;
             if (avail > 0) {
+#ifdef MIPT_TRACE_PROFILE
+                pRefills++;
+#endif
                 int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
                 if (cur == LANE_IDLE && prefix < avail) {
                     rayIdx = rangeNext + prefix;
@@ -155,6 +164,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         }
         if (nodeMask == 0 || __popcll(triMask) >= triVote) {
             // ---- triangle step: the exact triangle test on one triangle of the lane's leaf
+#ifdef MIPT_TRACE_PROFILE
+            pTriIters++;
+#endif
             if ((int32_t)cur < 0) {
                 uint32_t slot = cur & ~MIPT_LEAF_BIT;
                 float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
@@ -180,16 +192,20 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
             // ---- node steps, in a tight loop, until `triVote` lanes wait at a leaf or have finished
             int stay = __popcll(nodeMask) - nodeDrop;
             if (stay < 0) stay = 0;
+#ifdef MIPT_TRACE_PROFILE
+            pNodePhases++;
+#endif
             do {
+#ifdef MIPT_TRACE_PROFILE
+                pNodeIters++;
+#endif
                 if (cur < LANE_FINISHED) {
                     const uint4* nd = nodes + (size_t)cur * 2;
                     uint4 u0 = nd[0], u1 = nd[1];
                     nodeCount++;
                     float t0, t1;
-                    bool h0 = box_test(br, (float)(u0.x & 0xffffu), (float)(u0.x >> 16), (float)(u0.y & 0xffffu),
-                                       (float)(u0.y >> 16), (float)(u0.z & 0xffffu), (float)(u0.z >> 16), tcull, t0);
-                    bool h1 = box_test(br, (float)(u0.w & 0xffffu), (float)(u0.w >> 16), (float)(u1.x & 0xffffu),
-                                       (float)(u1.x >> 16), (float)(u1.y & 0xffffu), (float)(u1.y >> 16), tcull, t1);
+                    bool h0 = box_test(br, u0.x, u0.y, u0.z, tcull, t0);
+                    bool h1 = box_test(br, u0.w, u1.x, u1.y, tcull, t1);
                     uint32_t c0 = u1.z, c1 = u1.w;
                     if (h0 & h1) {                  // near child first, far child pushed
                         bool firstIs0 = t0 <= t1;
@@ -206,6 +222,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 }
             } while (__popcll(__ballot(cur < LANE_FINISHED)) > stay);
         }
+#ifdef MIPT_TRACE_PROFILE
+        { unsigned long long fm = __ballot(cur == LANE_FINISHED); if (fm) { pFinish++; pFinishLanes += __popcll(fm); } }
+#endif
         if (cur == LANE_FINISHED) {
             bool found = best.tri >= 0;
             if (MODE == 0) {
@@ -222,6 +241,14 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
+#ifdef MIPT_TRACE_PROFILE
+    if (lane == 0 && MODE == 0) {
+        atomicAdd(&stats[ST_PROF + 0], (unsigned long long)pOuter); atomicAdd(&stats[ST_PROF + 1], (unsigned long long)pNodeIters);
+        atomicAdd(&stats[ST_PROF + 2], (unsigned long long)pTriIters); atomicAdd(&stats[ST_PROF + 3], (unsigned long long)pNodePhases);
+        atomicAdd(&stats[ST_PROF + 4], (unsigned long long)pRefills); atomicAdd(&stats[ST_PROF + 5], (unsigned long long)pFinish);
+        atomicAdd(&stats[ST_PROF + 6], (unsigned long long)pFinishLanes);
+    }
+#endif
     if (lane == 0 && rs) {
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_RAYS : ST_SHADOW_RAYS], rs);
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_NODES : ST_SHADOW_NODES], ns);

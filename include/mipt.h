@@ -182,9 +182,10 @@ int mipt_scene_get_info(const mipt_scene* scene, mipt_scene_info* out);
 
 /* Copies the finished BVH to host memory for validation.  nodes: 8 uint32 per node slot
  * (num_node_slots of them): six words of 16-bit box coordinates on the grid returned by
- * mipt_scene_bvh_grid (coordinate = qmin + q * qcell; child 0 min xyz, max xyz, child 1 min
- * xyz, max xyz, low half first), then the two child codes (bit 31 = leaf, low bits = first
- * leaf slot); tri_v0/e1/e2: 4 floats per leaf slot. */
+ * mipt_scene_bvh_grid (coordinate = qmin + q * qcell; words 0-2 = child 0 x, y, z, words 3-5 =
+ * child 1 x, y, z, each word min | max << 16), then the two child codes (bit 31 = leaf, low
+ * bits = first leaf slot).  Slots that hold no node are zero.  tri_v0/e1/e2: 4 floats per leaf
+ * slot. */
 int mipt_scene_bvh_sizes(const mipt_scene* scene, int64_t* num_node_slots, int64_t* num_leaf_slots,
                          uint32_t* root_code);
 int mipt_scene_bvh_grid(const mipt_scene* scene, float qmin[3], float qcell[3]);

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B of library builds on the GPU box: runs the bench once per library given on the command line
+# (each is copied over csrc/libmipt.so of the box's scratch copy of the tree).
+# usage: bash profiles/ab_libs.sh <outdir> lib1.so lib2.so ...
+set -u
+OUT=$1; shift
+mkdir -p "$OUT"
+cp cuda-path-tracer_amd/csrc/libmipt.so "$OUT/base.so"
+for L in base "$@"; do
+  if [ "$L" != base ]; then cp "$L" cuda-path-tracer_amd/csrc/libmipt.so; else cp "$OUT/base.so" cuda-path-tracer_amd/csrc/libmipt.so; fi
+  name=$(basename "$L" .so)
+  timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1 || { echo "$name failed"; break; }
+  python3 -c "
+import json,sys; d=json.loads(open('$OUT/$name.log').read().strip().splitlines()[-1]); print('$name', round(d['ms_per_step'],1), 'closest', round(d['roofline']['avg_launch_ms'],2))"
+done
+rm -f "$OUT/base.so"

@@ -27,7 +27,8 @@ def validate_bvh(scene_host, dev_scene):
     tri_lo = np.minimum(np.minimum(p0, p1), p2)
     tri_hi = np.maximum(np.maximum(p0, p1), p2)
     codes = nodes[:, 6:8]
-    q = np.stack([nodes[:, :6] & 0xFFFF, nodes[:, :6] >> 16], axis=2).reshape(-1, 12).astype(np.float64)   # c0 min, c0 max, c1 min, c1 max
+    lo, hi = (nodes[:, :6] & 0xFFFF).reshape(-1, 2, 3), (nodes[:, :6] >> 16).reshape(-1, 2, 3)   # word = min | max << 16 per child and axis
+    q = np.stack([lo, hi], axis=2).reshape(-1, 12).astype(np.float64)   # c0 min, c0 max, c1 min, c1 max
     qmin, qcell = qmin.astype(np.float64), qcell.astype(np.float64)
     seen = np.zeros(n, dtype=bool)
     max_depth = 0
