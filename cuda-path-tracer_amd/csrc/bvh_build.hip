@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_emit_nodes(const BNode* __restrict__ no
 
 __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ attr, const int32_t* __restrict__ primIdx,
                                                   const int32_t* __restrict__ posNode, const BNode* __restrict__ nodes, int32_t n,
-                                                  float4* triV0, float4* triE1, float4* triE2)
+                                                  float4* tris)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -322,9 +322,11 @@ __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ at
     const float4* a = attr + (size_t)prim * 6;
     float4 p0 = a[0], p1 = a[2], p2 = a[4];
     uint32_t last = (p == nd.start + nd.count - 1) ? 1u : 0u;
-    triV0[p] = make_float4(p0.x, p0.y, p0.z, __uint_as_float((uint32_t)prim));
-    triE1[p] = make_float4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, __uint_as_float(last));
-    triE2[p] = make_float4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f);
+    float4* t = tris + (size_t)p * MIPT_TRI_F4;
+    t[0] = make_float4(p0.x, p0.y, p0.z, __uint_as_float((uint32_t)prim));
+    t[1] = make_float4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, __uint_as_float(last));
+    t[2] = make_float4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f);
+    for (int k = 3; k < MIPT_TRI_F4; k++) t[k] = make_float4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -379,9 +381,7 @@ void mipt_free_bvh(BvhResult* r)
 {
     if (!r) return;
     if (r->nodes) (void)hipFree(r->nodes);
-    if (r->triV0) (void)hipFree(r->triV0);
-    if (r->triE1) (void)hipFree(r->triE1);
-    if (r->triE2) (void)hipFree(r->triE2);
+    if (r->tris) (void)hipFree(r->tris);
     *r = BvhResult();
 }
 
@@ -471,12 +471,10 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     out->numNodeSlots = h.nodeCount;
     out->numLeafSlots = n;
     HIPCHK(hipMalloc(&out->nodes, sizeof(uint4) * 2 * (size_t)out->numNodeSlots));
-    HIPCHK(hipMalloc(&out->triV0, sizeof(float4) * (size_t)n));
-    HIPCHK(hipMalloc(&out->triE1, sizeof(float4) * (size_t)n));
-    HIPCHK(hipMalloc(&out->triE2, sizeof(float4) * (size_t)n));
+    HIPCHK(hipMalloc(&out->tris, sizeof(float4) * MIPT_TRI_F4 * (size_t)n));
     HIPCHK(hipMemsetAsync(&ctr->sah, 0, sizeof(double), stream));
     hipLaunchKernelGGL(k_emit_nodes, dim3((unsigned)((h.nodeCount + 255) / 256)), dim3(256), 0, stream, nodes, h.nodeCount, pad, grid, out->nodes, ctr);
-    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(256), 0, stream, d_attr, primIdx[cur], posNode[cur], nodes, n, out->triV0, out->triE1, out->triE2);
+    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(256), 0, stream, d_attr, primIdx[cur], posNode[cur], nodes, n, out->tris);
     HIPCHK(hipEventRecord(ev1, stream));
     HIPCHK(hipMemcpyAsync(&h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));

@@ -223,14 +223,15 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
 
     rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);
     if (rc) { mipt_scene_destroy(s); return fail(rc, "BVH build failed"); }
-    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 32 * (size_t)s->bvh.numNodeSlots + 48 * (size_t)s->bvh.numLeafSlots);
+    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 32 * (size_t)s->bvh.numNodeSlots + 16 * MIPT_TRI_F4 * (size_t)s->bvh.numLeafSlots);
 
     DevScene& D = s->dev;
-    D.nodes = s->bvh.nodes; D.triV0 = s->bvh.triV0; D.triE1 = s->bvh.triE1; D.triE2 = s->bvh.triE2;
+    D.nodes = s->bvh.nodes; D.tris = s->bvh.tris;
     D.attr = s->attr; D.triMat = s->triMat; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
     for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
     D.stackDepth = s->bvh.maxDepth + 2;
+    if (const char* e = getenv("MIPT_DEBUG_STACK")) D.stackDepth = atoi(e);   // timing experiments only: results are wrong when the stack overflows
     D.numTris = (int32_t)n; D.numMats = s->numMats;
     if ((size_t)D.stackDepth * 64 * 4 > 160 * 1024) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too deep for the LDS stack"); }
     *out = s;
@@ -268,9 +269,14 @@ int mipt_scene_download_bvh(const mipt_scene* s, uint32_t* nodes, float* v0, flo
 {
     if (!s) return fail(MIPT_E_INVALID, "null scene");
     if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 32 * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
-    if (v0 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(v0, s->bvh.triV0, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
-    if (e1 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e1, s->bvh.triE1, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
-    if (e2 && s->bvh.numLeafSlots) HIPTRY(hipMemcpy(e2, s->bvh.triE2, 16 * (size_t)s->bvh.numLeafSlots, hipMemcpyDeviceToHost));
+    if ((v0 || e1 || e2) && s->bvh.numLeafSlots) {
+        std::vector<float> rec((size_t)s->bvh.numLeafSlots * 4 * MIPT_TRI_F4);
+        HIPTRY(hipMemcpy(rec.data(), s->bvh.tris, rec.size() * 4, hipMemcpyDeviceToHost));
+        float* dst[3] = { v0, e1, e2 };
+        for (int k = 0; k < 3; k++)
+            if (dst[k])
+                for (int64_t i = 0; i < s->bvh.numLeafSlots; i++) memcpy(dst[k] + 4 * i, &rec[((size_t)i * MIPT_TRI_F4 + k) * 4], 16);
+    }
     return MIPT_OK;
 }
 

@@ -10,16 +10,19 @@
 // 32-byte-aligned record): the boxes of BOTH children live in the parent, so that one fetch
 // decides both descents.  Box coordinates are 16-bit cells of a uniform grid over the scene
 // (coordinate = qmin + q * qcell, minima rounded down, maxima rounded up after padding): the
-// box test only has to be generous, never tight, and the traversal is limited by the number of
-// per-lane memory requests it issues, so a node must cost as few 16-byte requests as possible.
-//   u0 = (c0min.x | c0min.y << 16, c0min.z | c0max.x << 16, c0max.y | c0max.z << 16, c1min.x | c1min.y << 16)
-//   u1 = (c1min.z | c1max.x << 16, c1max.y | c1max.z << 16, child0, child1)
-// A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  Leaf slots are three
-// parallel float4 arrays in BVH order (the three loads of a lane hit three arrays, consecutive
-// slots of one leaf are consecutive in each):
-//   triV0[s] = (v0.xyz, bits global triangle id)
-//   triE1[s] = (v1 - v0, bits 1 if last triangle of its leaf else 0)
-//   triE2[s] = (v2 - v0, 0)
+// box test only has to be generous, never tight.  One word per child and axis, min | max << 16:
+//   u0 = (c0.x, c0.y, c0.z, c1.x)      u1 = (c1.y, c1.z, child0, child1)
+// Four slots share a 128-byte line; the builder groups a node with its first inner descendants.
+// A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  A leaf slot is one
+// record of MIPT_TRI_F4 float4 in BVH order (triangles of one leaf are consecutive), so that the
+// three loads of a lane fall into one cache line: the traversal is limited by the number of
+// distinct lines its lanes touch, not by arithmetic.
+//   tris[s * MIPT_TRI_F4 + 0] = (v0.xyz, bits global triangle id)
+//   tris[s * MIPT_TRI_F4 + 1] = (v1 - v0, bits 1 if last triangle of its leaf else 0)
+//   tris[s * MIPT_TRI_F4 + 2] = (v2 - v0, 0)
+#ifndef MIPT_TRI_F4
+#define MIPT_TRI_F4 4      // 64-byte records: a record never straddles a 128-byte line
+#endif
 #define MIPT_LEAF_BIT 0x80000000u
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
@@ -38,9 +41,7 @@ struct DevMaterial {
 
 struct DevScene {
     const uint4*       nodes;
-    const float4*      triV0;
-    const float4*      triE1;
-    const float4*      triE2;
+    const float4*      tris;       // MIPT_TRI_F4 float4 per leaf slot
     const float4*      attr;       // 6 float4 per global triangle: three (pos3, normal3, uv2) corners
     const int32_t*     triMat;     // material per global triangle, -1 = none
     const DevMaterial* mats;
@@ -79,9 +80,7 @@ enum {
 struct BvhResult {
     uint4*   nodes = nullptr;     // numNodeSlots * 2
     float    qmin[3] = { 0, 0, 0 }, qcell[3] = { 1, 1, 1 };
-    float4*  triV0 = nullptr;
-    float4*  triE1 = nullptr;
-    float4*  triE2 = nullptr;
+    float4*  tris = nullptr;      // numLeafSlots * MIPT_TRI_F4
     int64_t  numNodeSlots = 0;
     int64_t  numLeafSlots = 0;
     int64_t  numInner = 0;

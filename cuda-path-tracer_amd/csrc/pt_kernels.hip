@@ -107,6 +107,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     const uint4* __restrict__ nodes = S.nodes;
     const int stackTop = S.stackDepth - 1;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+#ifdef MIPT_ABL_VALU
+    float t0dummy = 1.0f;
+#endif
 #ifdef MIPT_TRACE_PROFILE
     uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0;
 #endif
@@ -169,7 +172,8 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
 #endif
             if ((int32_t)cur < 0) {
                 uint32_t slot = cur & ~MIPT_LEAF_BIT;
-                float4 a = S.triV0[slot], b = S.triE1[slot], c = S.triE2[slot];
+                const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
+                float4 a = tr[0], b = tr[1], c = tr[2];
                 triCount++;
                 float t, u, v;
                 bool occluded = false;
@@ -202,10 +206,27 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 if (cur < LANE_FINISHED) {
                     const uint4* nd = nodes + (size_t)cur * 2;
                     uint4 u0 = nd[0], u1 = nd[1];
+#ifdef MIPT_ABL_LOAD      // sensitivity experiment: one more request (same line) per node step
+                    { uint32_t x = __builtin_nontemporal_load((const uint32_t*)nd + 5); asm volatile("" :: "v"(x)); }
+#endif
+#ifdef MIPT_ABL_VALU      // sensitivity experiment: twelve more vector instructions per node step
+                    { float z = t0dummy; asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0" : "+v"(z)); t0dummy = z; }
+#endif
                     nodeCount++;
                     float t0, t1;
                     bool h0 = box_test(br, u0.x, u0.y, u0.z, tcull, t0);
                     bool h1 = box_test(br, u0.w, u1.x, u1.y, tcull, t1);
+#ifdef MIPT_ABL_BOX2      // sensitivity experiment: the box arithmetic of a node step done twice
+                    {
+                        uint4 w0 = u0, w1 = u1;
+                        asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y));
+                        float s0, s1;
+                        bool g0 = box_test(br, w0.x, w0.y, w0.z, tcull, s0);
+                        bool g1 = box_test(br, w0.w, w1.x, w1.y, tcull, s1);
+                        float z = (g0 ? s0 : 0.0f) + (g1 ? s1 : 0.0f);
+                        asm volatile("" :: "v"(z));
+                    }
+#endif
                     uint32_t c0 = u1.z, c1 = u1.w;
                     if (h0 & h1) {                  // near child first, far child pushed
                         bool firstIs0 = t0 <= t1;

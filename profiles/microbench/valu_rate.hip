@@ -57,9 +57,14 @@ template <typename K> void run(const char* name, K k)
         hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, iters, d, sink);
         hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, iters, d, sink);
         hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0); hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, iters * 10, d, sink); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double nsPerInstr = ms * 1e6 / (iters * 10 * 32.0 * (threads / 256.0));
         double wavesPerSimd = threads / 256.0;
         // s_memtime ticks at 100 MHz; convert with the measured ratio printed by the mov row
         printf("%-10s waves/SIMD %.0f: %8.3f counter ticks per wave instruction\n", name, wavesPerSimd, (double)h[0] / (iters * 32.0 * wavesPerSimd));
+        printf("%-10s waves/SIMD %.0f: %8.3f ns of SIMD time per wave instruction (256 workgroups, events) = %.2f cycles at 2.4 GHz\n", name, wavesPerSimd, nsPerInstr, nsPerInstr * 2.4);
     }
     hipFree(d); hipFree(sink);
 }
