@@ -33,7 +33,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet, packed fp32 FMA
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TRI_TEST = 51              # full Moeller-Trumbore from three vertices
 FLOP_PER_BOX_TEST = 22
-BYTES_PER_NODE = 32                 # one node record = the 16-bit boxes of both children + links
+BYTES_PER_NODE_CHILD = 16          # a node slot holds, per child, a 12-byte box on the 16-bit grid and a 4-byte link
 BYTES_PER_TRI_TEST = 36             # three float3 positions
 
 
@@ -147,8 +147,9 @@ def main():
     if rank == 0:
         s0 = stats[-1]
         closest_s = tot[3].item() / 1e3                 # rank 0's closest-hit kernel time over the timed steps
-        flops = FLOP_PER_TRI_TEST * tot[1].item() + FLOP_PER_BOX_TEST * 2 * tot[2].item()
-        bytes_ = BYTES_PER_TRI_TEST * tot[1].item() + BYTES_PER_NODE * tot[2].item()
+        width = int(info.node_width)                    # child boxes tested per node visit
+        flops = FLOP_PER_TRI_TEST * tot[1].item() + FLOP_PER_BOX_TEST * width * tot[2].item()
+        bytes_ = BYTES_PER_TRI_TEST * tot[1].item() + BYTES_PER_NODE_CHILD * width * tot[2].item()
         achieved_tf = flops / closest_s / 1e12 if closest_s > 0 else 0.0
         launches = max(tot[4].item(), 1.0)
         result = {
@@ -162,7 +163,7 @@ def main():
                 "samples": samples, "global_illumination": bool(gi), "textures": True, "normal_maps": False,
                 "parallelism": f"{args.shard}x{world}", "rays_per_frame": total_rays / args.steps,
                 "render_time_s": elapsed / args.steps, "bvh_build_ms": info.build_ms, "bvh_depth": int(info.max_depth),
-                "bvh_sah_cost": info.sah_cost, "samples_per_pass": int(s0.chunk_samples),
+                "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "samples_per_pass": int(s0.chunk_samples),
             },
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",

@@ -332,40 +332,101 @@ __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ at
 // ---------------------------------------------------------------------------------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "bvh build: %s failed: %s\n", #x, hipGetErrorString(e_)); rc = MIPT_E_DEVICE; goto done; } } while (0)
 
-// Rewrites the node array in cache-line groups: four 32-byte slots share one 128-byte line, and a
-// line holds a node together with the first inner descendants reached from it (breadth first), so
-// that the step from a node to its child usually stays inside the line that is already in the
-// vector cache.  Leaves own no slot, so the array also shrinks to the inner nodes.
-static int relayout_nodes(BvhResult* out, hipStream_t stream)
+// ---------------------------------------------------------------------------------------
+// Wide nodes.  The builder's binary tree is collapsed into nodes with up to four children
+// (64 bytes: twelve box words and four child codes, see pt_internal.h): starting from the two
+// children of a binary node, the inner child with the largest surface is replaced by its own
+// two children until four are reached.  A traversal step then costs one cache line per lane for
+// two binary levels.  Two wide nodes share a 128-byte line: a node and its largest inner child.
+// Runs on the host over the downloaded binary nodes (a few milliseconds per 100 k triangles).
+struct WChild { uint32_t code; uint32_t w[3]; };     // w[a] = min | max << 16 on axis a
+
+static inline double wchild_area(const WChild& c, const float* qcell)
+{
+    double e[3];
+    for (int a = 0; a < 3; a++) e[a] = ((double)(c.w[a] >> 16) - (double)(c.w[a] & 0xffffu)) * qcell[a];
+    return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+}
+
+static int collapse_to_wide(BvhResult* out, hipStream_t stream)
 {
     const int64_t oldSlots = out->numNodeSlots;
-    if (oldSlots <= 0 || (out->rootCode & MIPT_LEAF_BIT)) return MIPT_OK;
+    if (oldSlots <= 0 || (out->rootCode & MIPT_LEAF_BIT)) { out->numInner = 0; out->maxDepth = 0; return MIPT_OK; }
     std::vector<uint32_t> src((size_t)oldSlots * 8);
     if (hipMemcpyAsync(src.data(), out->nodes, src.size() * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIPT_E_DEVICE;
     if (hipStreamSynchronize(stream) != hipSuccess) return MIPT_E_DEVICE;
-    std::vector<uint32_t> newIdx((size_t)oldSlots, MIPT_NO_NODE), order;   // order[new] = old
-    order.reserve((size_t)oldSlots);
-    std::vector<uint32_t> roots{ 0u }, group;
-    size_t head = 0;
-    while (head < roots.size()) {
-        group.clear(); group.push_back(roots[head++]);
-        for (size_t g = 0; g < group.size(); g++) {
-            for (int c = 0; c < 2; c++) {
-                uint32_t code = src[(size_t)group[g] * 8 + 6 + c];
-                if (code & MIPT_LEAF_BIT) continue;
-                if (group.size() < 4) group.push_back(code); else roots.push_back(code);
-            }
-        }
-        for (uint32_t o : group) { newIdx[o] = (uint32_t)order.size(); order.push_back(o); }
-        while (order.size() % 4) order.push_back(MIPT_NO_NODE);
-    }
-    std::vector<uint32_t> dst(order.size() * 8, 0u);
-    for (size_t i = 0; i < order.size(); i++) {
-        if (order[i] == MIPT_NO_NODE) continue;
-        memcpy(&dst[i * 8], &src[(size_t)order[i] * 8], 32);
+
+    struct Wide { WChild k[MIPT_NODE_WIDTH]; int n; };
+    auto make_wide = [&](uint32_t x) {
+        Wide W; W.n = 2;
         for (int c = 0; c < 2; c++) {
-            uint32_t code = dst[i * 8 + 6 + c];
-            if (!(code & MIPT_LEAF_BIT)) dst[i * 8 + 6 + c] = newIdx[code];
+            W.k[c].code = src[(size_t)x * 8 + 6 + c];
+            for (int a = 0; a < 3; a++) W.k[c].w[a] = src[(size_t)x * 8 + 3 * c + a];
+        }
+        while (W.n < MIPT_NODE_WIDTH) {
+            int best = -1; double bestArea = -1.0;
+            for (int i = 0; i < W.n; i++) {
+                if (W.k[i].code & MIPT_LEAF_BIT) continue;
+                double ar = wchild_area(W.k[i], out->qcell);
+                if (ar > bestArea) { bestArea = ar; best = i; }
+            }
+            if (best < 0) break;
+            uint32_t y = W.k[best].code;
+            for (int c = 0; c < 2; c++) {
+                WChild& d = (c == 0) ? W.k[best] : W.k[W.n];
+                d.code = src[(size_t)y * 8 + 6 + c];
+                for (int a = 0; a < 3; a++) d.w[a] = src[(size_t)y * 8 + 3 * c + a];
+            }
+            W.n++;
+        }
+        return W;
+    };
+
+    std::vector<uint32_t> slotOf((size_t)oldSlots, MIPT_NO_NODE);
+    std::vector<Wide> wide;                       // by slot; n = 0 marks an unused slot
+    struct Pending { uint32_t node; int32_t depth; };
+    std::vector<Pending> roots{ { 0u, 0 } };
+    int32_t maxDepth = 0; int64_t numWide = 0;
+    for (size_t head = 0; head < roots.size(); head++) {
+        const Pending r = roots[head];
+        slotOf[r.node] = (uint32_t)wide.size();
+        wide.push_back(make_wide(r.node)); numWide++;
+        const Wide W = wide.back();
+        if (r.depth + 1 > maxDepth) maxDepth = r.depth + 1;
+        int mate = -1; double mateArea = -1.0;
+        for (int i = 0; i < W.n; i++) {
+            if (W.k[i].code & MIPT_LEAF_BIT) continue;
+            double ar = wchild_area(W.k[i], out->qcell);
+            if (ar > mateArea) { mateArea = ar; mate = i; }
+        }
+        for (int i = 0; i < W.n; i++)
+            if (!(W.k[i].code & MIPT_LEAF_BIT) && i != mate) roots.push_back({ W.k[i].code, r.depth + 1 });
+        if (mate >= 0) {
+            uint32_t y = W.k[mate].code;
+            slotOf[y] = (uint32_t)wide.size();
+            wide.push_back(make_wide(y)); numWide++;
+            const Wide M = wide.back();
+            if (r.depth + 2 > maxDepth) maxDepth = r.depth + 2;
+            for (int i = 0; i < M.n; i++)
+                if (!(M.k[i].code & MIPT_LEAF_BIT)) roots.push_back({ M.k[i].code, r.depth + 2 });
+        } else {
+            Wide E; E.n = 0; wide.push_back(E);
+        }
+    }
+    std::vector<uint32_t> dst(wide.size() * 16, 0u);
+    for (size_t i = 0; i < wide.size(); i++) {
+        const Wide& W = wide[i];
+        if (W.n == 0) continue;
+        for (int k = 0; k < MIPT_NODE_WIDTH; k++) {
+            uint32_t* boxw = &dst[i * 16 + 3 * k];
+            if (k < W.n) {
+                boxw[0] = W.k[k].w[0]; boxw[1] = W.k[k].w[1]; boxw[2] = W.k[k].w[2];
+                uint32_t code = W.k[k].code;
+                dst[i * 16 + 12 + k] = (code & MIPT_LEAF_BIT) ? code : slotOf[code];
+            } else {
+                boxw[0] = boxw[1] = boxw[2] = 0x0000FFFFu;     // min above max: no ray enters an unused child
+                dst[i * 16 + 12 + k] = MIPT_NO_NODE;
+            }
         }
     }
     uint4* nn = nullptr;
@@ -373,7 +434,9 @@ static int relayout_nodes(BvhResult* out, hipStream_t stream)
     if (hipMemcpy(nn, dst.data(), dst.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(nn); return MIPT_E_DEVICE; }
     (void)hipFree(out->nodes);
     out->nodes = nn;
-    out->numNodeSlots = (int64_t)order.size();
+    out->numNodeSlots = (int64_t)wide.size();
+    out->numInner = numWide;
+    out->maxDepth = maxDepth;
     return MIPT_OK;
 }
 
@@ -491,13 +554,10 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         out->sahCost = ra > 0 ? h.sah / ra : 0.0;
     }
     {
-        const char* lay = getenv("MIPT_BVH_LAYOUT");
-        if (!lay || atoi(lay) != 0) {          // MIPT_BVH_LAYOUT=0 keeps the builder's breadth-first order (for comparison)
-            auto t0 = std::chrono::steady_clock::now();
-            rc = relayout_nodes(out, stream);
-            if (rc) goto done;
-            out->buildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        }
+        auto t0 = std::chrono::steady_clock::now();
+        rc = collapse_to_wide(out, stream);
+        if (rc) goto done;
+        out->buildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 done:
     if (primMin) (void)hipFree(primMin);

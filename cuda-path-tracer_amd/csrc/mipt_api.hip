@@ -38,6 +38,7 @@ struct mipt_scene {
     int32_t numMats = 0;
     int64_t geometryBytes = 0, textureBytes = 0;
     double uploadMs = 0;
+    uint32_t* stackSpill = nullptr;
     hipStream_t stream = nullptr;
 };
 
@@ -105,6 +106,7 @@ void mipt_scene_destroy(mipt_scene* s)
     if (s->mats) (void)hipFree(s->mats);
     if (s->texels) (void)hipFree(s->texels);
     if (s->texelsF) (void)hipFree(s->texelsF);
+    if (s->stackSpill) (void)hipFree(s->stackSpill);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -223,17 +225,25 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
 
     rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);
     if (rc) { mipt_scene_destroy(s); return fail(rc, "BVH build failed"); }
-    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 32 * (size_t)s->bvh.numNodeSlots + 16 * MIPT_TRI_F4 * (size_t)s->bvh.numLeafSlots);
+    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 16 * MIPT_NODE_WIDTH * (size_t)s->bvh.numNodeSlots + 16 * MIPT_TRI_F4 * (size_t)s->bvh.numLeafSlots);
 
     DevScene& D = s->dev;
     D.nodes = s->bvh.nodes; D.tris = s->bvh.tris;
     D.attr = s->attr; D.triMat = s->triMat; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
     for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
-    D.stackDepth = s->bvh.maxDepth + 2;
-    if (const char* e = getenv("MIPT_DEBUG_STACK")) D.stackDepth = atoi(e);   // timing experiments only: results are wrong when the stack overflows
+    // depth-first walk of a tree whose nodes push up to (width - 1) siblings per level
+    D.stackDepth = (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2;
+    D.stackLds = D.stackDepth < MIPT_STACK_LDS_MAX ? D.stackDepth : MIPT_STACK_LDS_MAX;
+    if (const char* e = getenv("MIPT_DEBUG_STACK")) D.stackLds = D.stackDepth = atoi(e);   // timing experiments only: results are wrong when the stack overflows
     D.numTris = (int32_t)n; D.numMats = s->numMats;
-    if ((size_t)D.stackDepth * 64 * 4 > 160 * 1024) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too deep for the LDS stack"); }
+    if (D.stackDepth > D.stackLds) {
+        // one slice per wave that can be resident: 32 per compute unit
+        size_t bytes = (size_t)(D.stackDepth - D.stackLds) * 64 * 4 * (size_t)g_numCUs * 32;
+        if (bytes > ((size_t)4 << 30)) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too deep for the traversal stack"); }
+        SCTRY(hipMalloc(&s->stackSpill, bytes));
+        D.stackSpill = s->stackSpill;
+    }
     *out = s;
     return MIPT_OK;
 }
@@ -246,6 +256,7 @@ int mipt_scene_get_info(const mipt_scene* s, mipt_scene_info* o)
     o->max_depth = s->bvh.maxDepth; o->num_materials = s->numMats;
     o->geometry_bytes = s->geometryBytes; o->texture_bytes = s->textureBytes;
     o->build_ms = s->bvh.buildMs; o->upload_ms = s->uploadMs; o->sah_cost = s->bvh.sahCost;
+    o->node_width = MIPT_NODE_WIDTH;
     return MIPT_OK;
 }
 
@@ -268,7 +279,7 @@ int mipt_scene_bvh_grid(const mipt_scene* s, float* qmin, float* qcell)
 int mipt_scene_download_bvh(const mipt_scene* s, uint32_t* nodes, float* v0, float* e1, float* e2)
 {
     if (!s) return fail(MIPT_E_INVALID, "null scene");
-    if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 32 * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
+    if (nodes && s->bvh.numNodeSlots) HIPTRY(hipMemcpy(nodes, s->bvh.nodes, 16 * MIPT_NODE_WIDTH * (size_t)s->bvh.numNodeSlots, hipMemcpyDeviceToHost));
     if ((v0 || e1 || e2) && s->bvh.numLeafSlots) {
         std::vector<float> rec((size_t)s->bvh.numLeafSlots * 4 * MIPT_TRI_F4);
         HIPTRY(hipMemcpy(rec.data(), s->bvh.tris, rec.size() * 4, hipMemcpyDeviceToHost));

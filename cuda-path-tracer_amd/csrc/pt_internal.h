@@ -6,13 +6,13 @@
 
 // ---- device-side scene --------------------------------------------------------------
 //
-// BVH node slot (32 B = 2 x uint4, fetched by one lane with two 16-byte loads from one
-// 32-byte-aligned record): the boxes of BOTH children live in the parent, so that one fetch
-// decides both descents.  Box coordinates are 16-bit cells of a uniform grid over the scene
+// BVH node slot (64 B = 4 x uint4, fetched by one lane with four 16-byte loads from one half of a
+// 128-byte line): the boxes of up to MIPT_NODE_WIDTH children live in the parent, so that one
+// fetch decides all descents.  Box coordinates are 16-bit cells of a uniform grid over the scene
 // (coordinate = qmin + q * qcell, minima rounded down, maxima rounded up after padding): the
 // box test only has to be generous, never tight.  One word per child and axis, min | max << 16:
-//   u0 = (c0.x, c0.y, c0.z, c1.x)      u1 = (c1.y, c1.z, child0, child1)
-// Four slots share a 128-byte line; the builder groups a node with its first inner descendants.
+//   words 3k .. 3k+2 = x, y, z of child k;  words 12 .. 15 = child codes
+// An unused child has min > max (word 0x0000FFFF) and code MIPT_NO_NODE.
 // A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  A leaf slot is one
 // record of MIPT_TRI_F4 float4 in BVH order (triangles of one leaf are consecutive), so that the
 // three loads of a lane fall into one cache line: the traversal is limited by the number of
@@ -23,6 +23,8 @@
 #ifndef MIPT_TRI_F4
 #define MIPT_TRI_F4 4      // 64-byte records: a record never straddles a 128-byte line
 #endif
+#define MIPT_NODE_WIDTH 4
+#define MIPT_STACK_LDS_MAX 22   // stack entries per lane kept in LDS (5.5 KiB per wave: 28 waves per compute unit)
 #define MIPT_LEAF_BIT 0x80000000u
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
@@ -50,7 +52,9 @@ struct DevScene {
     float              qmin[3];    // origin and cell size of the 16-bit grid the node boxes live on
     float              qcell[3];
     uint32_t           rootCode;   // MIPT_NO_NODE for an empty scene
-    int32_t            stackDepth; // entries of the per-lane traversal stack
+    int32_t            stackDepth; // entries of the per-lane traversal stack the tree can need
+    int32_t            stackLds;   // of these, entries kept in LDS; the rest live in stackSpill
+    uint32_t*          stackSpill; // (stackDepth - stackLds) * 64 entries per resident wave, or null
     int32_t            numTris;
     int32_t            numMats;
 };
@@ -78,7 +82,7 @@ enum {
 
 // ---- BVH build result -------------------------------------------------------------------
 struct BvhResult {
-    uint4*   nodes = nullptr;     // numNodeSlots * 2
+    uint4*   nodes = nullptr;     // numNodeSlots * 4
     float    qmin[3] = { 0, 0, 0 }, qcell[3] = { 1, 1, 1 };
     float4*  tris = nullptr;      // numLeafSlots * MIPT_TRI_F4
     int64_t  numNodeSlots = 0;

@@ -71,7 +71,8 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // Traversal kernels: TraceRays / Intersect of PathTracer.cu:193-288 over a queue of rays.
 //
 // One wave per workgroup, one ray per lane, per-lane stack in LDS (entry k of lane l at
-// stack[k * 64 + l]: every lane of a half-wave hits its own bank).  Waves are persistent: a wave
+// stack[k * 64 + l]: every lane of a half-wave hits its own bank; entries beyond the LDS part,
+// which only very deep trees need, live in a per-wave slice of global memory).  Waves are persistent: a wave
 // reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
 // as soon as they fall idle.
 //
@@ -79,9 +80,9 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // either ONE triangle step for the lanes that wait at a triangle (taken when `triVote` lanes wait
 // there or no lane is at an inner node), or a tight loop of node steps that runs until `nodeDrop`
 // of the lanes that entered it have left for a leaf or finished.  Lanes of the other kind sit the
-// phase out.  Both thresholds were chosen by measurement (profiles/): the kernel is limited by
-// the rate at which the memory pipeline accepts per-lane requests, not by vector issue, so long
-// node phases at falling lane occupancy cost less than frequent phase changes.
+// phase out.  A node step fetches one 64-byte node (one cache line per lane), tests its four
+// child boxes, sorts the children that were hit by entry distance, continues with the nearest
+// and pushes the others.  Both thresholds were chosen by measurement (profiles/).
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
@@ -90,9 +91,28 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
 #define TRACE_TRI_VOTE 16
-#define TRACE_NODE_DROP 48
+#define TRACE_NODE_DROP 32
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
 #define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
+
+__device__ __forceinline__ void stack_store(uint32_t* lds, uint32_t* spill, int ldsCap, int idx, uint32_t v)
+{
+    if (idx < ldsCap) lds[idx * WAVE] = v;
+    else if (spill) spill[(size_t)(idx - ldsCap) * WAVE] = v;       // no slice: the tree cannot need this entry
+}
+__device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32_t* spill, int ldsCap, int idx)
+{
+    if (idx < ldsCap) return lds[idx * WAVE];
+    return spill ? spill[(size_t)(idx - ldsCap) * WAVE] : LANE_FINISHED;
+}
+// compare-exchange of (key, code) pairs: afterwards ka <= kb
+__device__ __forceinline__ void order_pair(float& ka, uint32_t& ca, float& kb, uint32_t& cb)
+{
+    bool swap = kb < ka;
+    float kmin = fminf(ka, kb), kmax = fmaxf(ka, kb);
+    uint32_t cmin = swap ? cb : ca, cmax = swap ? ca : cb;
+    ka = kmin; kb = kmax; ca = cmin; cb = cmax;
+}
 
 template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
@@ -105,6 +125,8 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     uint32_t* stack = smem + lane;
     const int n = *d_count;
     const uint4* __restrict__ nodes = S.nodes;
+    const int ldsCap = S.stackLds;
+    uint32_t* spill = S.stackSpill ? S.stackSpill + (size_t)blockIdx.x * (size_t)(S.stackDepth - S.stackLds) * WAVE + lane : nullptr;
     const int stackTop = S.stackDepth - 1;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
 #ifdef MIPT_ABL_VALU
@@ -189,7 +211,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 bool last = __float_as_uint(b.w) != 0 || slot + 1 >= (uint32_t)S.numTris;
                 if (occluded) { cur = LANE_FINISHED; }
                 else if (!last) { cur = cur + 1; }
-                else if (sp > 0) { sp--; cur = stack[sp * WAVE]; }
+                else if (sp > 0) { sp--; cur = stack_load(stack, spill, ldsCap, sp); }
                 else { cur = LANE_FINISHED; }
             }
         } else {
@@ -204,39 +226,32 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 pNodeIters++;
 #endif
                 if (cur < LANE_FINISHED) {
-                    const uint4* nd = nodes + (size_t)cur * 2;
-                    uint4 u0 = nd[0], u1 = nd[1];
-#ifdef MIPT_ABL_LOAD      // sensitivity experiment: one more request (same line) per node step
-                    { uint32_t x = __builtin_nontemporal_load((const uint32_t*)nd + 5); asm volatile("" :: "v"(x)); }
-#endif
-#ifdef MIPT_ABL_VALU      // sensitivity experiment: twelve more vector instructions per node step
-                    { float z = t0dummy; asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0\n v_add_f32 %0, %0, %0" : "+v"(z)); t0dummy = z; }
-#endif
+                    const uint4* nd = nodes + (size_t)cur * 4;
+                    uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
                     nodeCount++;
-                    float t0, t1;
-                    bool h0 = box_test(br, u0.x, u0.y, u0.z, tcull, t0);
-                    bool h1 = box_test(br, u0.w, u1.x, u1.y, tcull, t1);
-#ifdef MIPT_ABL_BOX2      // sensitivity experiment: the box arithmetic of a node step done twice
-                    {
-                        uint4 w0 = u0, w1 = u1;
-                        asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y));
-                        float s0, s1;
-                        bool g0 = box_test(br, w0.x, w0.y, w0.z, tcull, s0);
-                        bool g1 = box_test(br, w0.w, w1.x, w1.y, tcull, s1);
-                        float z = (g0 ? s0 : 0.0f) + (g1 ? s1 : 0.0f);
-                        asm volatile("" :: "v"(z));
-                    }
-#endif
-                    uint32_t c0 = u1.z, c1 = u1.w;
-                    if (h0 & h1) {                  // near child first, far child pushed
-                        bool firstIs0 = t0 <= t1;
-                        stack[sp * WAVE] = firstIs0 ? c1 : c0;
-                        sp = (sp < stackTop) ? sp + 1 : sp;   // the builder sizes the stack; never write past it
-                        cur = firstIs0 ? c0 : c1;
-                    } else if (h0 | h1) {
-                        cur = h0 ? c0 : c1;
+                    // entry distance per child, +inf where the ray misses the child's box
+                    float k0, k1, k2, k3;
+                    k0 = box_test(br, w0.x, w0.y, w0.z, tcull, k0) ? k0 : INFINITY;
+                    k1 = box_test(br, w0.w, w1.x, w1.y, tcull, k1) ? k1 : INFINITY;
+                    k2 = box_test(br, w1.z, w1.w, w2.x, tcull, k2) ? k2 : INFINITY;
+                    k3 = box_test(br, w2.y, w2.z, w2.w, tcull, k3) ? k3 : INFINITY;
+                    uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
+                    // nearest first: five compare-exchanges sort the four (distance, child) pairs
+                    order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
+                    order_pair(k0, c0, k2, c2); order_pair(k1, c1, k3, c3);
+                    order_pair(k1, c1, k2, c2);
+                    // the children that were hit are the first `hits`; the nearest is visited now, the
+                    // others are pushed farthest first.  The builder sizes the stack for the tree.
+                    int hits = (k0 < INFINITY) + (k1 < INFINITY) + (k2 < INFINITY) + (k3 < INFINITY);
+                    if (sp + 3 > stackTop) sp = stackTop - 3;          // cannot happen for a tree of the stated depth
+                    if (k3 < INFINITY) stack_store(stack, spill, ldsCap, sp, c3);
+                    if (k2 < INFINITY) stack_store(stack, spill, ldsCap, sp + hits - 3, c2);
+                    if (k1 < INFINITY) stack_store(stack, spill, ldsCap, sp + hits - 2, c1);
+                    if (hits > 0) {
+                        sp += hits - 1;
+                        cur = c0;
                     } else if (sp > 0) {
-                        sp--; cur = stack[sp * WAVE];
+                        sp--; cur = stack_load(stack, spill, ldsCap, sp);
                     } else {
                         cur = LANE_FINISHED;
                     }
@@ -302,7 +317,7 @@ static size_t trace_smem(const DevScene& S)
 {
     static int extra = -1;      // MIPT_TRACE_LDS_EXTRA: additional bytes per wave, to study occupancy
     if (extra < 0) { const char* e = getenv("MIPT_TRACE_LDS_EXTRA"); extra = e ? atoi(e) : 0; }
-    return (size_t)S.stackDepth * WAVE * sizeof(uint32_t) + (size_t)extra;
+    return (size_t)S.stackLds * WAVE * sizeof(uint32_t) + (size_t)extra;
 }
 
 static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)

@@ -55,7 +55,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("num_triangles", C.c_int64), ("num_nodes", C.c_int64), ("num_leaves", C.c_int64),
                 ("max_depth", C.c_int32), ("num_materials", C.c_int32), ("geometry_bytes", C.c_int64),
                 ("texture_bytes", C.c_int64), ("build_ms", C.c_double), ("upload_ms", C.c_double),
-                ("sah_cost", C.c_double)]
+                ("sah_cost", C.c_double), ("node_width", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

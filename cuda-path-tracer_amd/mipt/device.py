@@ -90,7 +90,7 @@ class Scene:
     def download_bvh(self):
         ns, ls, root = C.c_int64(), C.c_int64(), C.c_uint32()
         _check(lib().mipt_scene_bvh_sizes(self._h, C.byref(ns), C.byref(ls), C.byref(root)))
-        nodes = np.zeros((ns.value, 8), dtype=np.uint32)
+        nodes = np.zeros((ns.value, 4 * self.info().node_width), dtype=np.uint32)
         v0 = np.zeros((ls.value, 4), dtype=np.float32)
         e1 = np.zeros((ls.value, 4), dtype=np.float32)
         e2 = np.zeros((ls.value, 4), dtype=np.float32)

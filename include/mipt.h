@@ -130,7 +130,7 @@ typedef struct mipt_build_options {
 
 typedef struct mipt_scene_info {
     int64_t num_triangles;           /* non-light triangles in the BVH */
-    int64_t num_nodes;               /* inner nodes */
+    int64_t num_nodes;               /* inner (wide) nodes */
     int64_t num_leaves;
     int32_t max_depth;               /* deepest leaf; root = 0 */
     int32_t num_materials;
@@ -138,7 +138,9 @@ typedef struct mipt_scene_info {
     int64_t texture_bytes;
     double  build_ms;                /* device time of the BVH build */
     double  upload_ms;               /* host flattening + H2D copies */
-    double  sah_cost;                /* SAH cost of the final tree */
+    double  sah_cost;                /* SAH cost of the binary tree the wide nodes are made from */
+    int32_t node_width;              /* children per node slot */
+    int32_t reserved;
 } mipt_scene_info;
 
 /* Device-side counters and timings of one mipt_frame_accumulate call. */
@@ -180,12 +182,12 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
 void mipt_scene_destroy(mipt_scene* scene);
 int mipt_scene_get_info(const mipt_scene* scene, mipt_scene_info* out);
 
-/* Copies the finished BVH to host memory for validation.  nodes: 8 uint32 per node slot
- * (num_node_slots of them): six words of 16-bit box coordinates on the grid returned by
- * mipt_scene_bvh_grid (coordinate = qmin + q * qcell; words 0-2 = child 0 x, y, z, words 3-5 =
- * child 1 x, y, z, each word min | max << 16), then the two child codes (bit 31 = leaf, low
- * bits = first leaf slot).  Slots that hold no node are zero.  tri_v0/e1/e2: 4 floats per leaf
- * slot. */
+/* Copies the finished BVH to host memory for validation.  nodes: 4 * node_width uint32 per node
+ * slot (num_node_slots of them): 3 * node_width words of 16-bit box coordinates on the grid
+ * returned by mipt_scene_bvh_grid (coordinate = qmin + q * qcell; words 3k .. 3k+2 = x, y, z of
+ * child k, each word min | max << 16; an unused child has min > max), then node_width child
+ * codes (bit 31 = leaf, low bits = first leaf slot; 0xFFFFFFFF = unused).  Slots that hold no
+ * node are zero.  tri_v0/e1/e2: 4 floats per leaf slot. */
 int mipt_scene_bvh_sizes(const mipt_scene* scene, int64_t* num_node_slots, int64_t* num_leaf_slots,
                          uint32_t* root_code);
 int mipt_scene_bvh_grid(const mipt_scene* scene, float qmin[3], float qcell[3]);

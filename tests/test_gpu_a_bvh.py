@@ -26,9 +26,11 @@ def validate_bvh(scene_host, dev_scene):
     assert set(np.unique(last)) <= {0, 1} and last[-1] == 1
     tri_lo = np.minimum(np.minimum(p0, p1), p2)
     tri_hi = np.maximum(np.maximum(p0, p1), p2)
-    codes = nodes[:, 6:8]
-    lo, hi = (nodes[:, :6] & 0xFFFF).reshape(-1, 2, 3), (nodes[:, :6] >> 16).reshape(-1, 2, 3)   # word = min | max << 16 per child and axis
-    q = np.stack([lo, hi], axis=2).reshape(-1, 12).astype(np.float64)   # c0 min, c0 max, c1 min, c1 max
+    W = info.node_width
+    assert nodes.shape[1] == 4 * W
+    codes = nodes[:, 3 * W:]
+    lo, hi = (nodes[:, :3 * W] & 0xFFFF).reshape(-1, W, 3), (nodes[:, :3 * W] >> 16).reshape(-1, W, 3)   # word = min | max << 16 per child and axis
+    q = np.stack([lo, hi], axis=2).reshape(-1, 6 * W).astype(np.float64)   # per child: min xyz, max xyz
     qmin, qcell = qmin.astype(np.float64), qcell.astype(np.float64)
     seen = np.zeros(n, dtype=bool)
     max_depth = 0
@@ -55,16 +57,21 @@ def validate_bvh(scene_host, dev_scene):
             continue
         inner += 1
         nd = q[code]
-        boxes = [(qmin + nd[0:3] * qcell, qmin + nd[3:6] * qcell), (qmin + nd[6:9] * qcell, qmin + nd[9:12] * qcell)]
-        for k in range(2):
-            clo, chi = boxes[k]
+        used = 0
+        for k in range(W):
+            ck = int(codes[code, k])
+            clo, chi = qmin + nd[6 * k:6 * k + 3] * qcell, qmin + nd[6 * k + 3:6 * k + 6] * qcell
+            if ck == 0xFFFFFFFF:
+                assert (clo > chi).all(), "an unused child must have an empty box"
+                continue
+            used += 1
             assert (clo <= chi).all()
             if lo is not None:      # nested up to the padding both levels carry
                 assert (clo >= lo - 1.01 * qcell).all() and (chi <= hi + 1.01 * qcell).all()
-            stack.append((int(codes[code, k]), depth + 1, clo, chi))
+            stack.append((ck, depth + 1, clo, chi))
+        assert used >= 2
     assert seen.all(), "some leaf slot is unreachable from the root"
     assert max_depth == info.max_depth and leaves == info.num_leaves and inner == info.num_nodes
-    assert info.max_depth + 2 <= 640
     return info
 
 
