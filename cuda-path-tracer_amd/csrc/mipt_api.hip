@@ -235,7 +235,10 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     // depth-first walk of a tree whose nodes push up to (width - 1) siblings per level
     D.stackDepth = (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2;
     D.stackLds = D.stackDepth < MIPT_STACK_LDS_MAX ? D.stackDepth : MIPT_STACK_LDS_MAX;
-    if (const char* e = getenv("MIPT_DEBUG_STACK")) D.stackLds = D.stackDepth = atoi(e);   // timing experiments only: results are wrong when the stack overflows
+    if (const char* e = getenv("MIPT_STACK_LDS")) {          // test hook: a small LDS part sends the stack through its global-memory slice
+        int v = atoi(e);
+        if (v >= 1 && v < D.stackLds) D.stackLds = v;
+    }
     D.numTris = (int32_t)n; D.numMats = s->numMats;
     if (D.stackDepth > D.stackLds) {
         // one slice per wave that can be resident: 32 per compute unit

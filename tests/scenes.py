@@ -40,3 +40,22 @@ def random_rays(scene, n, seed, inside_fraction=0.7, aimed=True):
     d[k:k + m] = dd
     d = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
     return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def scene_from_triangles(tris):
+    """mipt_scene_desc over raw triangles (n, 3, 3), one mesh, no material.  Returns (desc, keepalive)."""
+    import ctypes as C
+    tris = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+    n = tris.shape[0]
+    v = np.zeros((n, 3, 8), dtype=np.float32)
+    v[:, :, :3] = tris
+    v[:, :, 4] = 1.0
+    verts = (abi.Vertex * (3 * n)).from_buffer_copy(v.tobytes()) if n else None
+    mesh = (abi.Mesh * 1)(abi.Mesh(0, n, -1, 0))
+    desc = abi.SceneDesc()
+    desc.vertices = C.cast(verts, C.POINTER(abi.Vertex)) if n else None
+    desc.num_triangles = n
+    desc.meshes = C.cast(mesh, C.POINTER(abi.Mesh))
+    desc.num_meshes = 1
+    desc.num_materials = 0
+    return desc, (verts, mesh)

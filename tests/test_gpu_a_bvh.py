@@ -3,6 +3,7 @@ traversal test: a malformed tree must show up here, not as a hung kernel."""
 import numpy as np
 import pytest
 
+import scenes
 from mipt import abi, host
 
 pytestmark = pytest.mark.gpu
@@ -91,22 +92,7 @@ def test_bvh_atrium_small(gpu, atrium_small):
 def test_bvh_degenerate_inputs(gpu):
     # one triangle; many identical triangles (coincident centroids force splits by position);
     # zero-area and sliver triangles; an empty scene
-    def scene_from(tris):
-        tris = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)
-        n = tris.shape[0]
-        v = np.zeros((n, 3, 8), dtype=np.float32)
-        v[:, :, :3] = tris
-        v[:, :, 4] = 1.0
-        verts = (abi.Vertex * (3 * n)).from_buffer_copy(v.tobytes()) if n else None
-        mesh = (abi.Mesh * 1)(abi.Mesh(0, n, -1, 0))
-        desc = abi.SceneDesc()
-        import ctypes as C
-        desc.vertices = C.cast(verts, C.POINTER(abi.Vertex)) if n else None
-        desc.num_triangles = n
-        desc.meshes = C.cast(mesh, C.POINTER(abi.Mesh))
-        desc.num_meshes = 1
-        desc.num_materials = 0
-        return desc, (verts, mesh)
+    scene_from = scenes.scene_from_triangles
 
     import ctypes as C
     one = [[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]

@@ -76,3 +76,41 @@ def test_empty_and_ragged_batches(gpu, cornell, cornell_oracle):
     rays[3, 3:] = [0, -1, 0]
     rays[4, 3:] = [1e-38, -1, 0]
     assert_trace_parity(sc, cornell_oracle, rays)
+
+
+def test_deep_tree_uses_the_stack_beyond_lds(gpu):
+    """Nested shells of triangles whose sizes fall geometrically give a tall, thin tree; rays
+    through the common centre enter every child box on the way down, so the per-lane stack grows
+    past the part that is kept in LDS."""
+    import ctypes as C
+    tris = []
+    for i in range(120):
+        r = 100.0 * 0.8 ** i
+        for sx in (-1.0, 1.0):          # a small triangle on either side of the centre, at distance r
+            c = np.array([sx * r, 0.0, 0.0])
+            h = 0.2 * r
+            tris.append([c + [0, -h, -h], c + [0, h, -h], c + [0, 0, h]])
+    desc, keep = scenes.scene_from_triangles(tris)
+    sc = gpu.Scene(C.pointer(desc))
+    osc = ob.OracleScene(C.pointer(desc))
+    info = sc.info()
+    assert (info.node_width - 1) * info.max_depth + 2 > 22, "tree too shallow to leave the LDS part of the stack"
+    # rays start near the common centre and leave along +-x: the nearest children are the deepest
+    # ones, so every level leaves its outer (far) children on the stack
+    rng = np.random.default_rng(5)
+    n = 4096
+    rays = np.zeros((n, 6), dtype=np.float32)
+    rays[:, :3] = rng.normal(0, 1e-12, (n, 3))
+    d = np.stack([rng.choice([-1.0, 1.0], n), rng.normal(0, 0.1, n), rng.normal(0, 0.1, n)], axis=1)
+    rays[:, 3:] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    tri = assert_trace_parity(sc, osc, rays)
+    assert (tri >= 0).mean() > 0.1
+
+
+def test_stack_slice_in_global_memory(gpu, atrium_small, atrium_small_oracle, monkeypatch):
+    """With only two stack entries in LDS nearly every ray keeps part of its stack in the
+    global-memory slice of its wave; results must not change."""
+    monkeypatch.setenv("MIPT_STACK_LDS", "2")
+    sc = gpu.Scene(atrium_small.desc)
+    monkeypatch.delenv("MIPT_STACK_LDS")
+    assert_trace_parity(sc, atrium_small_oracle, scenes.random_rays(atrium_small, 20000, seed=11))
