@@ -105,13 +105,20 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32
     if (idx < ldsCap) return lds[idx * WAVE];
     return spill ? spill[(size_t)(idx - ldsCap) * WAVE] : LANE_FINISHED;
 }
-// compare-exchange of (key, code) pairs: afterwards ka <= kb
-__device__ __forceinline__ void order_pair(float& ka, uint32_t& ca, float& kb, uint32_t& cb)
+// compare-exchange of (key, code) pairs: afterwards ka <= kb.  Keys are the bit patterns of
+// non-negative floats (entry distances, +inf for a miss), which order like unsigned integers.
+#define KEY_MISS 0x7f800000u
+__device__ __forceinline__ void order_pair(uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb)
 {
     bool swap = kb < ka;
-    float kmin = fminf(ka, kb), kmax = fmaxf(ka, kb);
+    uint32_t kmin = ka < kb ? ka : kb, kmax = ka < kb ? kb : ka;
     uint32_t cmin = swap ? cb : ca, cmax = swap ? ca : cb;
     ka = kmin; kb = kmax; ca = cmin; cb = cmax;
+}
+__device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull)
+{
+    float t;
+    return box_test(r, wx, wy, wz, tcull, t) ? __float_as_uint(t) : KEY_MISS;
 }
 
 template <int MODE>
@@ -127,7 +134,6 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     const uint4* __restrict__ nodes = S.nodes;
     const int ldsCap = S.stackLds;
     uint32_t* spill = S.stackSpill ? S.stackSpill + (size_t)blockIdx.x * (size_t)(S.stackDepth - S.stackLds) * WAVE + lane : nullptr;
-    const int stackTop = S.stackDepth - 1;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
 #ifdef MIPT_ABL_VALU
     float t0dummy = 1.0f;
@@ -230,23 +236,25 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
                     nodeCount++;
                     // entry distance per child, +inf where the ray misses the child's box
-                    float k0, k1, k2, k3;
-                    k0 = box_test(br, w0.x, w0.y, w0.z, tcull, k0) ? k0 : INFINITY;
-                    k1 = box_test(br, w0.w, w1.x, w1.y, tcull, k1) ? k1 : INFINITY;
-                    k2 = box_test(br, w1.z, w1.w, w2.x, tcull, k2) ? k2 : INFINITY;
-                    k3 = box_test(br, w2.y, w2.z, w2.w, tcull, k3) ? k3 : INFINITY;
+                    uint32_t k0 = box_key(br, w0.x, w0.y, w0.z, tcull), k1 = box_key(br, w0.w, w1.x, w1.y, tcull);
+                    uint32_t k2 = box_key(br, w1.z, w1.w, w2.x, tcull), k3 = box_key(br, w2.y, w2.z, w2.w, tcull);
                     uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
                     // nearest first: five compare-exchanges sort the four (distance, child) pairs
                     order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
                     order_pair(k0, c0, k2, c2); order_pair(k1, c1, k3, c3);
                     order_pair(k1, c1, k2, c2);
-                    // the children that were hit are the first `hits`; the nearest is visited now, the
-                    // others are pushed farthest first.  The builder sizes the stack for the tree.
-                    int hits = (k0 < INFINITY) + (k1 < INFINITY) + (k2 < INFINITY) + (k3 < INFINITY);
-                    if (sp + 3 > stackTop) sp = stackTop - 3;          // cannot happen for a tree of the stated depth
-                    if (k3 < INFINITY) stack_store(stack, spill, ldsCap, sp, c3);
-                    if (k2 < INFINITY) stack_store(stack, spill, ldsCap, sp + hits - 3, c2);
-                    if (k1 < INFINITY) stack_store(stack, spill, ldsCap, sp + hits - 2, c1);
+                    // The children that were hit are the first `hits`; the nearest is visited now, the
+                    // others go on the stack, farthest deepest: child j lands at sp + hits - 1 - j.  For a
+                    // child that was missed that offset is negative; taken modulo 4 it points above the
+                    // new top of the stack, where the value is never read.  All three stores can thus be
+                    // unconditional (the stack has three spare entries).
+                    int hits = (k0 != KEY_MISS) + (k1 != KEY_MISS) + (k2 != KEY_MISS) + (k3 != KEY_MISS);
+                    int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
+                    if (__ballot(sp + 3 >= ldsCap) == 0) {
+                        stack[p1 * WAVE] = c1; stack[p2 * WAVE] = c2; stack[p3 * WAVE] = c3;
+                    } else {
+                        stack_store(stack, spill, ldsCap, p1, c1); stack_store(stack, spill, ldsCap, p2, c2); stack_store(stack, spill, ldsCap, p3, c3);
+                    }
                     if (hits > 0) {
                         sp += hits - 1;
                         cur = c0;
