@@ -55,10 +55,30 @@ def cpu_baseline(scene, cam, params, budget_s=15.0):
     _, _, _, st = osc.render(cam, params, accel=ob.ACCEL_OCTREE, row_step=step, row_phase=step // 2, threads=threads)
     rows_done = len(range(step // 2, h, step))
     rays = st.closest_rays + st.shadow_rays
-    return {
+    out = {
         "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": st.threads, "kind": "port",
         "sample": f"{rows_done} of {h} image rows (every {step}th), {rays} rays in {st.seconds:.1f} s, octree search, OpenMP",
     }
+    # the reference's CPU path is serial (one thread renders the image): the same restatement on one core,
+    # on the middle row of the image only
+    step1 = h
+    _, _, _, s1 = osc.render(cam, params, accel=ob.ACCEL_OCTREE, row_step=step1, row_phase=step1 // 2, threads=1)
+    out["single_thread_value"] = (s1.closest_rays + s1.shadow_rays) / s1.seconds / 1e6
+    out["single_thread_sample"] = f"{len(range(step1 // 2, h, step1))} rows, {s1.seconds:.1f} s"
+    return out
+
+
+def measured_traffic(workload):
+    """HBM-side bytes per launch of the closest-hit kernel from the committed counter run
+    (profiles/traffic.json, written by profiles/pmc_report.py from separate FETCH_SIZE and
+    WRITE_SIZE passes of this same command); None when there is no entry for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(workload)
+        return float(e["bytes_per_launch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def main():
@@ -168,7 +188,8 @@ def main():
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
                 "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(args.workload),
+                "algorithmic_bytes_per_launch": bytes_ / launches,
                 "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
                 "triangle_tests_per_s": tot[1].item() / closest_s if closest_s > 0 else 0.0,
                 "node_visits_per_s": tot[2].item() / closest_s if closest_s > 0 else 0.0,

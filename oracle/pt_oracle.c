@@ -656,11 +656,18 @@ int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p,
     int nt = 1; (void)threads;
 #endif
     double t0 = now_s();
+    /* work items are 32-pixel pieces of the sampled rows, so that a sample of a few rows still
+     * keeps every thread busy; pixels are independent (the random stream is keyed by the pixel) */
+    const long PIECE = 32;
+    long nRows = 0;
+    for (long h = 0; h < H; ++h) if ((h % row_step) == row_phase) nRows++;
+    const long piecesPerRow = (W + PIECE - 1) / PIECE;
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nt) reduction(+:closest,shadow,tt,bt)
-    for (long h = 0; h < H; ++h) {
-        if ((h % row_step) != row_phase) continue;
+    for (long item = 0; item < nRows * piecesPerRow; ++item) {
+        long h = row_phase + (item / piecesPerRow) * row_step;
+        long j0 = (item % piecesPerRow) * PIECE, j1 = j0 + PIECE < W ? j0 + PIECE : W;
         rctx R; R.s = s; R.p = p; R.accel = accel; R.closest = R.shadow = R.tri_tests = R.box_tests = 0;
-        for (long j = 0; j < W; ++j) {
+        for (long j = j0; j < j1; ++j) {
             float o[3], d[3];
             pto_primary_ray(cam, (int32_t)j, (int32_t)h, o, d);
             int32_t tri = -1;

@@ -13,8 +13,28 @@ for r in rows:
         print("  wave instrs: VALU %.3g SALU %.3g VMEM_RD %.3g LDS %.3g" % (f("SQ_INSTS_VALU"), f("SQ_INSTS_SALU"), f("SQ_INSTS_VMEM_RD"), f("SQ_INSTS_LDS")))
         print("  wave time: waiting %.2f, issue-stalled %.2f, issuing %.2f" % (f("SQ_WAIT_ANY") / wc, f("SQ_WAIT_INST_ANY") / wc, f("SQ_ACTIVE_INST_ANY") / wc))
         print("  resident waves per SIMD          %.2f" % (4 * wc / cyc / 1024))
-        print("  VALU pipe busy (4 cyc per wave64 op) %.2f" % (f("SQ_INSTS_VALU") * 4 / 1024 / cyc))
+        print("  VALU issue, INSTS_VALU x 4 cycles over SIMD cycles (upper estimate: simple ops measure 2.2-2.7 cycles) %.2f" % (f("SQ_INSTS_VALU") * 4 / 1024 / cyc))
         print("  TA busy                          %.2f" % (f("TA_BUSY_avr") / cyc))
         print("  L1 accesses %.3g, L1->L2 %.3g (L1 hit %.2f), L2 hit %.2f, fabric reads %.3g, FETCH_SIZE %.1f GB, WRITE_SIZE %.2f GB" % (
             f("TCP_TOTAL_CACHE_ACCESSES_sum"), f("TCP_TCC_READ_REQ_sum"), 1 - f("TCP_TCC_READ_REQ_sum") / max(f("TCP_TOTAL_CACHE_ACCESSES_sum"), 1),
             f("TCC_HIT_sum") / max(f("TCC_REQ_sum"), 1), f("TCC_EA0_RDREQ_sum"), f("FETCH_SIZE") / 1e6, f("WRITE_SIZE") / 1e6))
+
+# optional second argument: write the memory-side traffic of the closest-hit kernel per launch
+# (FETCH_SIZE and WRITE_SIZE are KiB at the L2's fabric side, Infinity-Cache hits included; on gfx950
+# FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled) for bench.py to report
+if len(sys.argv) > 3:
+    import json
+    out, workload = sys.argv[2], sys.argv[3]
+    for r in rows:
+        if "k_trace<0>" in r["kernel"]:
+            calls = float(r["calls"])
+            fetch, write = float(r["FETCH_SIZE"]) * 1024, float(r["WRITE_SIZE"]) * 1024
+            try:
+                table = json.load(open(out))
+            except (OSError, ValueError):
+                table = {}
+            table[workload] = {"bytes_per_launch": (2 * fetch + write) / calls, "fetch_size_bytes_raw": fetch / calls,
+                               "write_size_bytes": write / calls, "launches_profiled": int(calls),
+                               "note": "2 x FETCH_SIZE + WRITE_SIZE per launch of k_trace<0>; fabric side of L2, Infinity Cache hits included"}
+            json.dump(table, open(out, "w"), indent=1)
+            print("traffic per launch: %.2f GB" % (table[workload]["bytes_per_launch"] / 1e9))

@@ -19,7 +19,7 @@ for a in la:
     for b in lb:
         env = dict(os.environ, **{va: a, vb: b})
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra, env=env,
-                           capture_output=True, text=True, timeout=300)
+                           capture_output=True, text=True, timeout=90)
         if p.returncode != 0:
             row.append("FAIL")
             continue
