@@ -29,8 +29,9 @@ typedef struct mipt_host_scene mipt_host_scene;
  * group, the first three vertices of each face, optional winding flip (Cornell box,
  * MainFrm.cpp:217,380-383), diffuse stored BGR, meshes ordered by triangle count
  * descending (a stable sort; the reference's std::sort is unstable).  Texture files
- * are decoded when they are PNG; a material whose files are missing keeps its
- * diffuse colour.  Returns NULL on failure. */
+ * are decoded when they are PNG.  A material that names a diffuse texture which cannot
+ * be loaded is left out of the material table, as in MainFrm.cpp:258-262: meshes that use
+ * it then have no material (index -1).  Returns NULL on failure. */
 mipt_host_scene* mipt_host_scene_load_obj(const char* path, int32_t flip_winding);
 
 /* Deterministic procedural atrium used as a labelled stand-in for the Sponza meshes
