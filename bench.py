@@ -27,6 +27,8 @@ WORKLOADS = {
     "sponza_gi128_1080p": ("sponza", 66000, 1024, 128, 1, 1920, 1080, 1),
     "sponza_direct_1080p": ("sponza", 66000, 1024, 64, 0, 1920, 1080, 1),
     "crytek_gi16_270p": ("crytek", 262000, 256, 16, 1, 1920, 1080, 4),
+    # 38 shifted instances flattened into one ~10 M-triangle list, 3840x2160, 512 samples
+    "crytek38x_gi512_2160p": ("crytek", 262000, 1024, 512, 1, 3840, 2160, 1, 38),
 }
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet, packed fp32 FMA
@@ -107,11 +109,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device.init(local_rank)
 
-    kind_name, tris, tex, samples, gi, width, height, div = WORKLOADS[args.workload]
+    kind_name, tris, tex, samples, gi, width, height, div = WORKLOADS[args.workload][:8]
+    copies = WORKLOADS[args.workload][8] if len(WORKLOADS[args.workload]) > 8 else 1
     tris = args.tris or tris
     samples = args.samples or samples
     kind = {"crytek": abi.SCENE_CRYTEK, "sponza": abi.SCENE_SPONZA}[kind_name]
     scene = host.HostScene.atrium(kind, tris, tex, 1)
+    if copies > 1:
+        scene = scene.instanced(copies, 4000.0 if kind == abi.SCENE_CRYTEK else 40.0)
     cam, sun = host.camera_preset(kind, width, height, div)
     dev = device.Scene(scene.desc, sah_bins=int(os.environ.get("MIPT_BENCH_BINS", "0")),
                        max_leaf_triangles=int(os.environ.get("MIPT_BENCH_LEAF", "0")),
