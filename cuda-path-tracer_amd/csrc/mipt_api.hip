@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <atomic>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -61,6 +62,8 @@ struct mipt_frame {
     unsigned long long* stats = nullptr;
     std::vector<hipEvent_t> events;
     int32_t lastActive = 0;
+    int32_t samplesDone = 0;                  // first-bounce samples summed into d_accum by the last accumulate call
+    std::atomic<int> cancel{ 0 };
 };
 
 extern "C" {
@@ -478,6 +481,8 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
 
     int32_t nAct = 0;
     int32_t usedChunk = 0;
+    bool cancelled = false;
+    f->samplesDone = 0;
     if (R.gi) {
         HIPTRY(hipMemcpyAsync(&nAct, f->counters + 4, 4, hipMemcpyDeviceToHost, st));
         HIPTRY(hipStreamSynchronize(st));
@@ -515,10 +520,15 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     spanEnd();
                 }
                 launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);
+                f->samplesDone = n0 + Sn - sb;
                 if (progress) {
+                    // the sums so far are handed over before every call-back, so that the caller can
+                    // look at (or finalize) a partial image from inside it
+                    launch_scatter_accum(f->pixAccum, f->actPix, nAct, d_accum, st);
                     HIPTRY(hipStreamSynchronize(st));
                     progress(total * (n0 + Sn - sb) / (se - sb), total, user);
                 }
+                if (f->cancel.load(std::memory_order_relaxed)) { cancelled = true; break; }
             }
             launch_scatter_accum(f->pixAccum, f->actPix, nAct, d_accum, st);
         }
@@ -527,6 +537,8 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     HIPTRY(hipStreamSynchronize(st));
     HIPTRY(hipGetLastError());
     if (progress && !(R.gi && nAct > 0)) progress(total, total, user);
+    if (!cancelled && f->cancel.load(std::memory_order_relaxed)) cancelled = true;     // asked for during the last pass or before the call
+    f->cancel.store(0, std::memory_order_relaxed);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         unsigned long long h[ST_COUNT];
@@ -551,20 +563,40 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         if (hipEventElapsedTime(&tot, f->events[0], f->events[evEndIdx]) == hipSuccess) stats->total_ms = tot;
         stats->shade_ms = stats->total_ms - stats->closest_ms - stats->shadow_ms;
         stats->chunk_samples = usedChunk;
+        stats->samples_done = f->samplesDone;
     }
+    if (cancelled) return fail(MIPT_E_CANCELLED, "cancelled after %d samples", f->samplesDone);
+    return MIPT_OK;
+}
+
+int mipt_frame_finalize_partial(mipt_frame* f, const float* d_accum, int32_t samples, float* d_out)
+{
+    if (!f || !d_accum || !d_out) return fail(MIPT_E_INVALID, "null argument");
+    if (samples < 0 || samples > f->R.numSamples) return fail(MIPT_E_INVALID, "sample count %d outside 0..%d", samples, f->R.numSamples);
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevRender R = f->R;
+    R.numSamples = samples > 0 ? samples : 1;        // no samples: the sums are zero, direct light only
+    launch_finalize(R, f->pixState, d_accum, d_out, f->stream);
+    HIPTRY(hipStreamSynchronize(f->stream));
+    HIPTRY(hipGetLastError());
     return MIPT_OK;
 }
 
 int mipt_frame_finalize(mipt_frame* f, const float* d_accum, float* d_out)
 {
-    if (!f || !d_accum || !d_out) return fail(MIPT_E_INVALID, "null argument");
-    int rc = ensure_init();
-    if (rc) return rc;
-    launch_finalize(f->R, f->pixState, d_accum, d_out, f->stream);
-    HIPTRY(hipStreamSynchronize(f->stream));
-    HIPTRY(hipGetLastError());
+    if (!f) return fail(MIPT_E_INVALID, "null argument");
+    return mipt_frame_finalize_partial(f, d_accum, f->R.numSamples, d_out);
+}
+
+int mipt_frame_cancel(mipt_frame* f)
+{
+    if (!f) return fail(MIPT_E_INVALID, "null argument");
+    f->cancel.store(1, std::memory_order_relaxed);
     return MIPT_OK;
 }
+
+int32_t mipt_frame_samples_done(const mipt_frame* f) { return f ? f->samplesDone : 0; }
 
 int mipt_frame_primary_ids(mipt_frame* f, int32_t* out)
 {

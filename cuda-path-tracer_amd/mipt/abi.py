@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("closest_triangle_tests", C.c_uint64), ("active_pixels", C.c_uint64), ("reserved0", C.c_uint64),
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("closest_launches", C.c_int32), ("shadow_launches", C.c_int32),
-                ("chunk_samples", C.c_int32), ("reserved1", C.c_int32)]
+                ("chunk_samples", C.c_int32), ("samples_done", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -73,11 +73,14 @@ class Stats(C.Structure):
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)
 
 # every symbol include/mipt.h declares
+E_CANCELLED = -5
+
 MIPT_SYMBOLS = [
     "mipt_init", "mipt_last_error", "mipt_device_name", "mipt_scene_create", "mipt_scene_destroy",
     "mipt_scene_get_info", "mipt_scene_bvh_sizes", "mipt_scene_bvh_grid", "mipt_scene_download_bvh", "mipt_trace_rays",
     "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_set_params", "mipt_frame_accumulate",
-    "mipt_frame_finalize", "mipt_frame_primary_ids", "mipt_frame_num_pixels", "mipt_render",
+    "mipt_frame_finalize", "mipt_frame_finalize_partial", "mipt_frame_cancel", "mipt_frame_samples_done",
+    "mipt_frame_primary_ids", "mipt_frame_num_pixels", "mipt_render",
     "mipt_device_alloc", "mipt_device_free", "mipt_copy_to_host", "mipt_copy_to_device",
     "mipt_device_synchronize",
 ]

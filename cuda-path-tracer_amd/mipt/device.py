@@ -18,6 +18,11 @@ class MiptError(RuntimeError):
     pass
 
 
+class MiptCancelled(MiptError):
+    """mipt_frame_accumulate was ended by mipt_frame_cancel; .stats holds the partial call's statistics."""
+    stats = None
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -42,6 +47,10 @@ def lib():
         L.mipt_frame_set_params.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Params)]
         L.mipt_frame_accumulate.argtypes = [vp, vp, C.POINTER(abi.Stats), abi.PROGRESS_FN, vp]
         L.mipt_frame_finalize.argtypes = [vp, vp, vp]
+        L.mipt_frame_finalize_partial.argtypes = [vp, vp, i32, vp]
+        L.mipt_frame_cancel.argtypes = [vp]
+        L.mipt_frame_samples_done.argtypes = [vp]
+        L.mipt_frame_samples_done.restype = i32
         L.mipt_frame_primary_ids.argtypes = [vp, vp]
         L.mipt_frame_num_pixels.argtypes = [vp]
         L.mipt_frame_num_pixels.restype = i64
@@ -149,13 +158,29 @@ class Frame:
         _check(lib().mipt_frame_set_params(self._h, C.byref(cam), C.byref(params)))
 
     def accumulate(self, d_accum_ptr, progress=None):
+        """mipt_frame_accumulate.  Raises MiptCancelled (stats attached) if cancel() ended it early."""
         st = abi.Stats()
         cb = abi.PROGRESS_FN(progress) if progress else _NO_PROGRESS
-        _check(lib().mipt_frame_accumulate(self._h, C.c_void_p(d_accum_ptr), C.byref(st), cb, None))
+        rc = lib().mipt_frame_accumulate(self._h, C.c_void_p(d_accum_ptr), C.byref(st), cb, None)
+        if rc == abi.E_CANCELLED:
+            e = MiptCancelled(lib().mipt_last_error().decode())
+            e.stats = st
+            raise e
+        _check(rc)
         return st
+
+    def cancel(self):
+        _check(lib().mipt_frame_cancel(self._h))
+
+    @property
+    def samples_done(self):
+        return lib().mipt_frame_samples_done(self._h)
 
     def finalize(self, d_accum_ptr, d_out_ptr):
         _check(lib().mipt_frame_finalize(self._h, C.c_void_p(d_accum_ptr), C.c_void_p(d_out_ptr)))
+
+    def finalize_partial(self, d_accum_ptr, samples, d_out_ptr):
+        _check(lib().mipt_frame_finalize_partial(self._h, C.c_void_p(d_accum_ptr), int(samples), C.c_void_p(d_out_ptr)))
 
     def primary_ids(self):
         w, h = self.size

@@ -36,6 +36,7 @@ extern "C" {
 #define MIPT_E_DEVICE     -2   /* HIP runtime error */
 #define MIPT_E_NOMEM      -3   /* host or device allocation failed */
 #define MIPT_E_LIMIT      -4   /* a size exceeds what the library supports */
+#define MIPT_E_CANCELLED  -5   /* mipt_frame_cancel ended the call early; partial sums are valid */
 
 /* texel formats of mipt_material::tex_format / nml_format */
 #define MIPT_TEX_NONE   0
@@ -160,7 +161,7 @@ typedef struct mipt_stats {
     int32_t  closest_launches;
     int32_t  shadow_launches;
     int32_t  chunk_samples;          /* samples per pass actually used */
-    int32_t  reserved1;
+    int32_t  samples_done;           /* first-bounce samples summed into d_accum (all of them unless cancelled) */
 } mipt_stats;
 
 /* Replaces CPTCallback::UpdateProgress (PTProgress.h:3-7).  Called on the calling
@@ -218,6 +219,17 @@ int mipt_frame_accumulate(mipt_frame* frame, float* d_accum, mipt_stats* stats,
 /* Applies PathTracer.cu:453-462 and :550-552 to the reduced sums: d_out (DEVICE,
  * 3 floats per pixel) = 255 * min(1, (direct + I * sum / N) * albedo / pi). */
 int mipt_frame_finalize(mipt_frame* frame, const float* d_accum, float* d_out_bgr255);
+/* Cancel and partial results.  The reference has neither (README.md:45: a render cannot be
+ * stopped; its poll loop, PathTracer.cu:719-733, only reports progress).  mipt_frame_cancel may be
+ * called from the progress call-back or from another thread; mipt_frame_accumulate then stops
+ * after the pass of samples it is in, leaves the sums of the samples done so far in d_accum and
+ * returns MIPT_E_CANCELLED.  A cancel asked for while no call runs ends the next call after its
+ * first pass.  Whenever the call-back runs, d_accum already holds the sums of
+ * mipt_frame_samples_done() samples, and mipt_frame_finalize_partial turns them into an image
+ * (the final formula with N = samples): a caller can show the picture as it converges. */
+int mipt_frame_cancel(mipt_frame* frame);
+int32_t mipt_frame_samples_done(const mipt_frame* frame);
+int mipt_frame_finalize_partial(mipt_frame* frame, const float* d_accum, int32_t samples, float* d_out_bgr255);
 /* Primary-hit triangle ids of the last accumulate call (HOST buffer, one per pixel). */
 int mipt_frame_primary_ids(mipt_frame* frame, int32_t* out_tri);
 int64_t mipt_frame_num_pixels(const mipt_frame* frame);

@@ -168,3 +168,36 @@ def test_invalid_arguments_are_rejected(gpu, cornell):
     cam0 = abi.Camera.from_buffer_copy(bytes(cam)); cam0.div = 0
     with pytest.raises(gpu.MiptError):
         sc.render(cam0, host.default_params(sun_pos=sun))
+
+
+def test_cancel_and_partial_image(gpu, cornell):
+    """Cancel from the progress call-back: the call stops after the pass it is in, the partial sums
+    equal those of a render with that many samples, and every call-back sees a usable partial image."""
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    npx = 240 * 135
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=8, chunk_samples=2)
+    fr = gpu.Frame(sc, cam, prm)
+    acc, out = gpu.DeviceBuffer(npx * 12), gpu.DeviceBuffer(npx * 12)
+    previews = []
+
+    def progress(done, total, user):
+        if done > 0:
+            fr.finalize_partial(acc.ptr, fr.samples_done, out.ptr)
+            previews.append((fr.samples_done, out.to_host().reshape(135, 240, 3).copy()))
+        if fr.samples_done == 4:
+            fr.cancel()
+
+    with pytest.raises(gpu.MiptCancelled) as ei:
+        fr.accumulate(acc.ptr, progress=progress)
+    assert ei.value.stats.samples_done == 4 and fr.samples_done == 4
+    assert [n for n, _ in previews] == [2, 4]
+    for n, img in previews:
+        ref, _, _ = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=n))
+        assert np.array_equal(img, ref), f"partial image after {n} samples"
+    # the flag is consumed: the next call runs to the end
+    st = fr.accumulate(acc.ptr)
+    assert st.samples_done == 8
+    fr.finalize(acc.ptr, out.ptr)
+    ref, _, _ = sc.render(cam, prm)
+    assert np.array_equal(out.to_host().reshape(135, 240, 3), ref)
