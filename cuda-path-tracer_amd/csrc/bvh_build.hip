@@ -455,7 +455,7 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     if (numTris >= (1ll << 30)) return MIPT_E_LIMIT;
     int rc = MIPT_OK;
     const int32_t n = (int32_t)numTris;
-    int nb = (opt && opt->sah_bins > 0) ? opt->sah_bins : 16;
+    int nb = (opt && opt->sah_bins > 0) ? opt->sah_bins : 32;
     if (nb < 2) nb = 2;
     if (nb > MAX_BINS) nb = MAX_BINS;
     int maxLeaf = (opt && opt->max_leaf_triangles > 0) ? opt->max_leaf_triangles : 4;

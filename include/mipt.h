@@ -123,7 +123,7 @@ typedef struct mipt_params {
 } mipt_params;
 
 typedef struct mipt_build_options {
-    int32_t sah_bins;                /* 0 = 16 */
+    int32_t sah_bins;                /* 0 = 32 (the maximum) */
     int32_t max_leaf_triangles;      /* 0 = 4 */
     float   traversal_cost;          /* 0 = 1.0 (in units of one triangle test) */
     int32_t reserved;
