@@ -36,4 +36,9 @@ def reduce_to_rank0(accum, dist=None, world=1):
     gloo) into rank 0's.  One collective per frame."""
     if world > 1:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if getattr(accum, "is_cuda", False):
+            # the collective runs on the communicator's stream and the render library on its own:
+            # the host waits here so that the finalize kernel cannot start before the sum is complete
+            import torch
+            torch.cuda.current_stream().synchronize()
     return accum
