@@ -103,11 +103,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MIPT_BENCH_BACKEND=gloo rehearses the multi-rank flow where the ranks have to share GPUs (the
+    # sums then travel through host memory); the real run uses one GPU per rank and RCCL
+    backend = os.environ.get("MIPT_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device.init(local_rank)
+    coll = "cuda" if backend == "nccl" else "cpu"      # where tensors handed to collectives live
 
     kind_name, tris, tex, samples, gi, width, height, div = WORKLOADS[args.workload][:8]
     copies = WORKLOADS[args.workload][8] if len(WORKLOADS[args.workload]) > 8 else 1
@@ -133,7 +139,13 @@ def main():
 
     def step():
         st = frame.accumulate(accum.data_ptr())
-        sharding.reduce_to_rank0(accum, dist, world)
+        if world > 1 and coll == "cpu":
+            host_sum = accum.cpu()
+            sharding.reduce_to_rank0(host_sum, dist, world)
+            if rank == 0:
+                accum.copy_(host_sum)
+        else:
+            sharding.reduce_to_rank0(accum, dist, world)
         if rank == 0:
             frame.finalize(accum.data_ptr(), out.data_ptr())
         return st
@@ -157,8 +169,8 @@ def main():
         float(sum(s.closest_ms for s in stats)), float(sum(s.closest_launches for s in stats)),
         float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
         float(sum(s.shadow_ms for s in stats)), float(sum(s.closest_rays for s in stats)),
-    ], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ], dtype=torch.float64, device=coll)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # rays and counters add over ranks; kernel time is per-rank wall time of rank 0's kernels
@@ -170,6 +182,8 @@ def main():
     elapsed = tmax.item()
 
     if rank == 0:
+        import hashlib
+        image_sha1 = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()   # tile shards add up bit for bit: same hash at any N
         s0 = stats[-1]
         closest_s = tot[3].item() / 1e3                 # rank 0's closest-hit kernel time over the timed steps
         width = int(info.node_width)                    # child boxes tested per node visit
@@ -188,7 +202,7 @@ def main():
                 "samples": samples, "global_illumination": bool(gi), "textures": True, "normal_maps": False,
                 "parallelism": f"{args.shard}x{world}", "rays_per_frame": total_rays / args.steps,
                 "render_time_s": elapsed / args.steps, "bvh_build_ms": info.build_ms, "bvh_depth": int(info.max_depth),
-                "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "samples_per_pass": int(s0.chunk_samples),
+                "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "image_sha1": image_sha1, "samples_per_pass": int(s0.chunk_samples),
             },
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
