@@ -62,24 +62,55 @@ __device__ __forceinline__ float box_area(const float* mn, const float* mx)
 }
 
 // ---------------------------------------------------------------------------------------
+// Atomics to one address are served at a fixed, low rate (tens per microsecond), so every kernel
+// below first combines what the 64 lanes of a wave (or the 256 threads of a block) have for the
+// same target and sends one atomic for the group.
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+// true if every active lane of the wave holds the same value
+__device__ __forceinline__ bool wave_uniform_i32(int32_t v)
+{
+    return __ballot(v != __builtin_amdgcn_readfirstlane(v)) == 0;
+}
+
 __global__ void __launch_bounds__(256) k_prim_bounds(const float4* __restrict__ attr, int32_t n, float4* primMin,
                                                     float4* primMax, int32_t* primIdx, int32_t* posNode, BNode* root)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4* a = attr + (size_t)i * 6;
-    float4 p0 = a[0], p1 = a[2], p2 = a[4];
-    float mnx = fminf(p0.x, fminf(p1.x, p2.x)), mny = fminf(p0.y, fminf(p1.y, p2.y)), mnz = fminf(p0.z, fminf(p1.z, p2.z));
-    float mxx = fmaxf(p0.x, fmaxf(p1.x, p2.x)), mxy = fmaxf(p0.y, fmaxf(p1.y, p2.y)), mxz = fmaxf(p0.z, fmaxf(p1.z, p2.z));
-    primMin[i] = make_float4(mnx, mny, mnz, 0);
-    primMax[i] = make_float4(mxx, mxy, mxz, 0);
-    primIdx[i] = i;
-    posNode[i] = 0;
-    float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy), cz = 0.5f * (mnz + mxz);
-    atomicMin(&root->bminI[0], f2key(mnx)); atomicMin(&root->bminI[1], f2key(mny)); atomicMin(&root->bminI[2], f2key(mnz));
-    atomicMax(&root->bmaxI[0], f2key(mxx)); atomicMax(&root->bmaxI[1], f2key(mxy)); atomicMax(&root->bmaxI[2], f2key(mxz));
-    atomicMin(&root->cminI[0], f2key(cx)); atomicMin(&root->cminI[1], f2key(cy)); atomicMin(&root->cminI[2], f2key(cz));
-    atomicMax(&root->cmaxI[0], f2key(cx)); atomicMax(&root->cmaxI[1], f2key(cy)); atomicMax(&root->cmaxI[2], f2key(cz));
+    int32_t kmin[3] = { INT_MAX, INT_MAX, INT_MAX }, kmax[3] = { INT_MIN, INT_MIN, INT_MIN };
+    int32_t cmin[3] = { INT_MAX, INT_MAX, INT_MAX }, cmax[3] = { INT_MIN, INT_MIN, INT_MIN };
+    if (i < n) {
+        const float4* a = attr + (size_t)i * 6;
+        float4 p0 = a[0], p1 = a[2], p2 = a[4];
+        float mnx = fminf(p0.x, fminf(p1.x, p2.x)), mny = fminf(p0.y, fminf(p1.y, p2.y)), mnz = fminf(p0.z, fminf(p1.z, p2.z));
+        float mxx = fmaxf(p0.x, fmaxf(p1.x, p2.x)), mxy = fmaxf(p0.y, fmaxf(p1.y, p2.y)), mxz = fmaxf(p0.z, fmaxf(p1.z, p2.z));
+        primMin[i] = make_float4(mnx, mny, mnz, 0);
+        primMax[i] = make_float4(mxx, mxy, mxz, 0);
+        primIdx[i] = i;
+        posNode[i] = 0;
+        float cx = 0.5f * (mnx + mxx), cy = 0.5f * (mny + mxy), cz = 0.5f * (mnz + mxz);
+        kmin[0] = f2key(mnx); kmin[1] = f2key(mny); kmin[2] = f2key(mnz);
+        kmax[0] = f2key(mxx); kmax[1] = f2key(mxy); kmax[2] = f2key(mxz);
+        cmin[0] = cmax[0] = f2key(cx); cmin[1] = cmax[1] = f2key(cy); cmin[2] = cmax[2] = f2key(cz);
+    }
+    for (int a = 0; a < 3; a++) {
+        kmin[a] = wave_min_i32(kmin[a]); kmax[a] = wave_max_i32(kmax[a]);
+        cmin[a] = wave_min_i32(cmin[a]); cmax[a] = wave_max_i32(cmax[a]);
+    }
+    if ((threadIdx.x & 63) == 0 && kmin[0] != INT_MAX) {
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&root->bminI[a], kmin[a]); atomicMax(&root->bmaxI[a], kmax[a]);
+            atomicMin(&root->cminI[a], cmin[a]); atomicMax(&root->cmaxI[a], cmax[a]);
+        }
+    }
 }
 
 __global__ void k_init_root(BNode* nodes, BuildCounters* ctr, int32_t* active, int32_t n)
@@ -112,26 +143,88 @@ __device__ __forceinline__ int bin_of(float c, float cmin, float cmax, int nb)
     return b < 0 ? 0 : (b >= nb ? nb - 1 : b);
 }
 
+// Positions of one node are contiguous, so a block that walks BIN_CHUNK consecutive positions sees
+// few nodes.  Triangles of a large node are binned into a copy of that node's bins in LDS, which
+// is added to the global bins when the block moves on to another node; triangles of small nodes
+// (little contention) go to the global bins directly.
+#define BIN_CHUNK 2048
+#define BIN_LDS_MIN_COUNT 512
 __global__ void __launch_bounds__(256) k_bin(const int32_t* __restrict__ primIdx, const int32_t* __restrict__ posNode,
                                             const BNode* __restrict__ nodes, const float4* __restrict__ primMin,
                                             const float4* __restrict__ primMax, Bin* bins, int32_t n, int nb)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const BNode& nd = nodes[posNode[p]];
-    if (nd.state != NODE_ACTIVE) return;
-    int prim = primIdx[p];
-    float4 mn = primMin[prim], mx = primMax[prim];
-    const float c[3] = { 0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z) };
-    int kmin[3] = { f2key(mn.x), f2key(mn.y), f2key(mn.z) }, kmax[3] = { f2key(mx.x), f2key(mx.y), f2key(mx.z) };
-    Bin* base = bins + (size_t)nd.activeSlot * 3 * nb;
-    for (int a = 0; a < 3; a++) {
-        int b = bin_of(c[a], key2f(nd.cminI[a]), key2f(nd.cmaxI[a]), nb);
-        Bin* B = base + a * nb + b;
-        atomicMin(&B->minI[0], kmin[0]); atomicMin(&B->minI[1], kmin[1]); atomicMin(&B->minI[2], kmin[2]);
-        atomicMax(&B->maxI[0], kmax[0]); atomicMax(&B->maxI[1], kmax[1]); atomicMax(&B->maxI[2], kmax[2]);
-        atomicAdd(&B->count, 1);
+    __shared__ int32_t lds[3 * MAX_BINS * 7];     // per bin: min xyz, max xyz, count
+    __shared__ int32_t ldsNode;                   // node whose bins are in LDS, -1 = none
+    const int nEntries = 3 * nb;
+    const int t = threadIdx.x;
+    if (t == 0) ldsNode = -1;
+    auto clear_lds = [&]() {
+        for (int e = t; e < nEntries; e += 256) {
+            int32_t* L = lds + e * 7;
+            L[0] = L[1] = L[2] = INT_MAX; L[3] = L[4] = L[5] = INT_MIN; L[6] = 0;
+        }
+    };
+    auto flush_lds = [&](int node) {
+        Bin* base = bins + (size_t)nodes[node].activeSlot * 3 * nb;
+        for (int e = t; e < nEntries; e += 256) {
+            const int32_t* L = lds + e * 7;
+            if (L[6] == 0) continue;
+            Bin* B = base + e;
+            atomicMin(&B->minI[0], L[0]); atomicMin(&B->minI[1], L[1]); atomicMin(&B->minI[2], L[2]);
+            atomicMax(&B->maxI[0], L[3]); atomicMax(&B->maxI[1], L[4]); atomicMax(&B->maxI[2], L[5]);
+            atomicAdd(&B->count, L[6]);
+        }
+    };
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * BIN_CHUNK;
+    for (int step = 0; step < BIN_CHUNK / 256; step++) {
+        const int64_t p0 = first + (int64_t)step * 256;
+        if (p0 >= n) break;
+        // the node of the step's first position decides which node may use LDS in this step
+        int want = posNode[p0];
+        const BNode& wn = nodes[want];
+        if (!(wn.state == NODE_ACTIVE && wn.count >= BIN_LDS_MIN_COUNT)) want = -1;
+        int have = ldsNode;
+        if (have != want) {                       // uniform over the block
+            if (have >= 0) flush_lds(have);
+            __syncthreads();
+            if (want >= 0) clear_lds();
+            if (t == 0) ldsNode = want;
+            __syncthreads();
+        }
+        const int64_t p = p0 + t;
+        if (p < n) {
+            const int id = posNode[p];
+            const BNode& nd = nodes[id];
+            if (nd.state == NODE_ACTIVE) {
+                int prim = primIdx[p];
+                float4 mn = primMin[prim], mx = primMax[prim];
+                const float c[3] = { 0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z) };
+                int kmin[3] = { f2key(mn.x), f2key(mn.y), f2key(mn.z) }, kmax[3] = { f2key(mx.x), f2key(mx.y), f2key(mx.z) };
+                if (id == want) {
+                    for (int a = 0; a < 3; a++) {
+                        int b = bin_of(c[a], key2f(nd.cminI[a]), key2f(nd.cmaxI[a]), nb);
+                        int32_t* L = lds + (a * nb + b) * 7;
+                        atomicMin(&L[0], kmin[0]); atomicMin(&L[1], kmin[1]); atomicMin(&L[2], kmin[2]);
+                        atomicMax(&L[3], kmax[0]); atomicMax(&L[4], kmax[1]); atomicMax(&L[5], kmax[2]);
+                        atomicAdd(&L[6], 1);
+                    }
+                } else {
+                    Bin* base = bins + (size_t)nd.activeSlot * 3 * nb;
+                    for (int a = 0; a < 3; a++) {
+                        int b = bin_of(c[a], key2f(nd.cminI[a]), key2f(nd.cmaxI[a]), nb);
+                        Bin* B = base + a * nb + b;
+                        atomicMin(&B->minI[0], kmin[0]); atomicMin(&B->minI[1], kmin[1]); atomicMin(&B->minI[2], kmin[2]);
+                        atomicMax(&B->maxI[0], kmax[0]); atomicMax(&B->maxI[1], kmax[1]); atomicMax(&B->maxI[2], kmax[2]);
+                        atomicAdd(&B->count, 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
+    int have = ldsNode;
+    if (have >= 0) flush_lds(have);
 }
 
 __device__ __forceinline__ void make_child(BNode* nodes, int id, const BNode& parent, int start, int count,
@@ -232,30 +325,81 @@ __global__ void __launch_bounds__(256) k_partition(const int32_t* __restrict__ p
                                                   const float4* __restrict__ primMin, const float4* __restrict__ primMax,
                                                   int32_t n, int nb)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    int id = posNode[p];
-    int prim = primIdx[p];
-    BNode& nd = nodes[id];
-    if (nd.state != NODE_INNER) {        // finished leaf: stays where it is
+    // every lane stays to the end: the wave-wide reductions below need all 64 lanes running
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = p < n;
+    int id = valid ? posNode[p] : 0;
+    int prim = valid ? primIdx[p] : 0;
+    bool moves = valid && nodes[id].state == NODE_INNER;
+    if (valid && !moves) {               // finished leaf: stays where it is
         primIdxOut[p] = prim; posNodeOut[p] = id;
+    }
+    const unsigned long long movers = __ballot(moves);
+    if (movers == 0) return;             // uniform
+    BNode& nd = nodes[moves ? id : 0];
+    bool goLeft = false;
+    int32_t ck[3] = { 0, 0, 0 }, bmn[3] = { 0, 0, 0 }, bmx[3] = { 0, 0, 0 };
+    if (moves) {
+        float4 mn = primMin[prim], mx = primMax[prim];
+        const float c[3] = { 0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z) };
+        if (nd.axis >= 0) goLeft = bin_of(c[nd.axis], key2f(nd.cminI[nd.axis]), key2f(nd.cmaxI[nd.axis]), nb) < nd.splitBin;
+        else goLeft = (p - nd.start) < nd.nLeft;
+        ck[0] = f2key(c[0]); ck[1] = f2key(c[1]); ck[2] = f2key(c[2]);
+        bmn[0] = f2key(mn.x); bmn[1] = f2key(mn.y); bmn[2] = f2key(mn.z);
+        bmx[0] = f2key(mx.x); bmx[1] = f2key(mx.y); bmx[2] = f2key(mx.z);
+    }
+    // When all moving lanes share ONE node (the usual case near the top of the tree, where a node
+    // spans many waves) the wave takes its places on either side with one atomic per side and sends
+    // one set of bounds per child.
+    const int leader = __ffsll((long long)movers) - 1;
+    const int leaderId = __shfl(id, leader);
+    const bool sameNode = __ballot(moves && id != leaderId) == 0;
+    if (sameNode) {
+        const unsigned long long lmask = __ballot(moves && goLeft), rmask = movers & ~lmask;
+        int baseL = 0, baseR = 0;
+        if (lane == leader) {
+            if (lmask) baseL = atomicAdd(&nd.fillL, __popcll(lmask));
+            if (rmask) baseR = atomicAdd(&nd.fillR, __popcll(rmask));
+        }
+        baseL = __shfl(baseL, leader); baseR = __shfl(baseR, leader);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (moves) {
+            int dst = goLeft ? nd.start + baseL + __popcll(lmask & below) : nd.start + nd.nLeft + baseR + __popcll(rmask & below);
+            primIdxOut[dst] = prim;
+            posNodeOut[dst] = nd.left + (goLeft ? 0 : 1);
+        }
+        const int axisL = __shfl(moves ? nd.axis : 0, leader), leftL = __shfl(moves ? nd.left : 0, leader);
+        const bool gather = axisL < 0;
+        for (int side = 0; side < 2; side++) {
+            if (((side == 0) ? lmask : rmask) == 0) continue;          // uniform
+            const bool mine = moves && ((side == 0) == goLeft);
+            int32_t vmin[3], vmax[3], wmin[3] = { 0, 0, 0 }, wmax[3] = { 0, 0, 0 };
+            for (int a = 0; a < 3; a++) {
+                vmin[a] = wave_min_i32(mine ? ck[a] : INT_MAX); vmax[a] = wave_max_i32(mine ? ck[a] : INT_MIN);
+                if (gather) { wmin[a] = wave_min_i32(mine ? bmn[a] : INT_MAX); wmax[a] = wave_max_i32(mine ? bmx[a] : INT_MIN); }
+            }
+            if (lane == leader) {
+                BNode& ch = nodes[leftL + side];
+                for (int a = 0; a < 3; a++) {
+                    atomicMin(&ch.cminI[a], vmin[a]); atomicMax(&ch.cmaxI[a], vmax[a]);
+                    if (gather) { atomicMin(&ch.bminI[a], wmin[a]); atomicMax(&ch.bmaxI[a], wmax[a]); }
+                }
+            }
+        }
         return;
     }
-    float4 mn = primMin[prim], mx = primMax[prim];
-    const float c[3] = { 0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z) };
-    bool goLeft;
-    if (nd.axis >= 0) goLeft = bin_of(c[nd.axis], key2f(nd.cminI[nd.axis]), key2f(nd.cmaxI[nd.axis]), nb) < nd.splitBin;
-    else goLeft = (p - nd.start) < nd.nLeft;
+    if (!moves) return;
     int child = nd.left + (goLeft ? 0 : 1);
     int dst = goLeft ? nd.start + atomicAdd(&nd.fillL, 1) : nd.start + nd.nLeft + atomicAdd(&nd.fillR, 1);
     primIdxOut[dst] = prim;
     posNodeOut[dst] = child;
     BNode& ch = nodes[child];
-    atomicMin(&ch.cminI[0], f2key(c[0])); atomicMin(&ch.cminI[1], f2key(c[1])); atomicMin(&ch.cminI[2], f2key(c[2]));
-    atomicMax(&ch.cmaxI[0], f2key(c[0])); atomicMax(&ch.cmaxI[1], f2key(c[1])); atomicMax(&ch.cmaxI[2], f2key(c[2]));
+    atomicMin(&ch.cminI[0], ck[0]); atomicMin(&ch.cminI[1], ck[1]); atomicMin(&ch.cminI[2], ck[2]);
+    atomicMax(&ch.cmaxI[0], ck[0]); atomicMax(&ch.cmaxI[1], ck[1]); atomicMax(&ch.cmaxI[2], ck[2]);
     if (nd.axis < 0) {
-        atomicMin(&ch.bminI[0], f2key(mn.x)); atomicMin(&ch.bminI[1], f2key(mn.y)); atomicMin(&ch.bminI[2], f2key(mn.z));
-        atomicMax(&ch.bmaxI[0], f2key(mx.x)); atomicMax(&ch.bmaxI[1], f2key(mx.y)); atomicMax(&ch.bmaxI[2], f2key(mx.z));
+        atomicMin(&ch.bminI[0], bmn[0]); atomicMin(&ch.bminI[1], bmn[1]); atomicMin(&ch.bminI[2], bmn[2]);
+        atomicMax(&ch.bmaxI[0], bmx[0]); atomicMax(&ch.bmaxI[1], bmx[1]); atomicMax(&ch.bmaxI[2], bmx[2]);
     }
 }
 
@@ -333,111 +477,154 @@ __global__ void __launch_bounds__(256) k_emit_tris(const float4* __restrict__ at
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "bvh build: %s failed: %s\n", #x, hipGetErrorString(e_)); rc = MIPT_E_DEVICE; goto done; } } while (0)
 
 // ---------------------------------------------------------------------------------------
-// Wide nodes.  The builder's binary tree is collapsed into nodes with up to four children
-// (64 bytes: twelve box words and four child codes, see pt_internal.h): starting from the two
-// children of a binary node, the inner child with the largest surface is replaced by its own
-// two children until four are reached.  A traversal step then costs one cache line per lane for
-// two binary levels.  Two wide nodes share a 128-byte line: a node and its largest inner child.
-// Runs on the host over the downloaded binary nodes (a few milliseconds per 100 k triangles).
+// Wide nodes.  The binary tree is collapsed into nodes with up to four children (64 bytes: twelve
+// box words and four child codes, see pt_internal.h): starting from the two children of a binary
+// node, the inner child with the largest surface is replaced by its own two children until four
+// are reached.  A traversal step then costs one cache line per lane for two binary levels.  Two
+// wide nodes share a 128-byte line: a node and its largest inner child.
+//
+// One launch per level of the binary tree, top down (the node ids of a level are contiguous, the
+// host knows the ranges from the build rounds): a binary node that has been given a slot becomes a
+// wide node, absorbs up to two descendants and hands slots to its inner children, which lie on
+// deeper levels and are reached by later launches.
 struct WChild { uint32_t code; uint32_t w[3]; };     // w[a] = min | max << 16 on axis a
+struct CollapseCounters { int32_t lines; int32_t maxDepth; int32_t numWide; int32_t pad; };
 
-static inline double wchild_area(const WChild& c, const float* qcell)
+__device__ __forceinline__ float wchild_area(const WChild& c, float cx, float cy, float cz)
 {
-    double e[3];
-    for (int a = 0; a < 3; a++) e[a] = ((double)(c.w[a] >> 16) - (double)(c.w[a] & 0xffffu)) * qcell[a];
-    return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    float ex = ((float)(c.w[0] >> 16) - (float)(c.w[0] & 0xffffu)) * cx;
+    float ey = ((float)(c.w[1] >> 16) - (float)(c.w[1] & 0xffffu)) * cy;
+    float ez = ((float)(c.w[2] >> 16) - (float)(c.w[2] & 0xffffu)) * cz;
+    return ex * ey + ey * ez + ez * ex;
 }
 
-static int collapse_to_wide(BvhResult* out, hipStream_t stream)
+__global__ void __launch_bounds__(256) k_collapse_level(const uint4* __restrict__ bin2, int32_t first, int32_t last,
+                                                       uint32_t* slotOf, int32_t* depthOf, float cx, float cy, float cz,
+                                                       uint4* wide, CollapseCounters* cc)
+{
+    const int x = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= last) return;
+    const uint32_t slot = slotOf[x];
+    if (slot == MIPT_NO_NODE) return;                 // a leaf, or absorbed by its parent
+    WChild k[MIPT_NODE_WIDTH];
+    int n = 2;
+    auto load2 = [&](int node, WChild& c0, WChild& c1) {
+        uint4 u0 = bin2[(size_t)node * 2], u1 = bin2[(size_t)node * 2 + 1];
+        c0.w[0] = u0.x; c0.w[1] = u0.y; c0.w[2] = u0.z; c0.code = u1.z;
+        c1.w[0] = u0.w; c1.w[1] = u1.x; c1.w[2] = u1.y; c1.code = u1.w;
+    };
+    load2(x, k[0], k[1]);
+    while (n < MIPT_NODE_WIDTH) {
+        int best = -1; float bestArea = -1.0f;
+        for (int i = 0; i < n; i++) {
+            if (k[i].code & MIPT_LEAF_BIT) continue;
+            float ar = wchild_area(k[i], cx, cy, cz);
+            if (ar > bestArea) { bestArea = ar; best = i; }
+        }
+        if (best < 0) break;
+        WChild c0, c1;
+        load2((int)k[best].code, c0, c1);
+        // constant indices only, so that k[] stays in registers
+        for (int i = 0; i < MIPT_NODE_WIDTH; i++) if (i == best) k[i] = c0;
+        for (int i = 0; i < MIPT_NODE_WIDTH; i++) if (i == n) k[i] = c1;
+        n++;
+    }
+    const int depth = depthOf[x];
+    int mate = -1;
+    if ((slot & 1u) == 0) {                            // first slot of a line: the largest inner child shares the line
+        float mateArea = -1.0f;
+        for (int i = 0; i < n; i++) {
+            if (k[i].code & MIPT_LEAF_BIT) continue;
+            float ar = wchild_area(k[i], cx, cy, cz);
+            if (ar > mateArea) { mateArea = ar; mate = i; }
+        }
+    }
+    uint32_t words[16];
+    for (int i = 0; i < MIPT_NODE_WIDTH; i++) {
+        if (i < n) {
+            words[3 * i] = k[i].w[0]; words[3 * i + 1] = k[i].w[1]; words[3 * i + 2] = k[i].w[2];
+            uint32_t code = k[i].code;
+            if (!(code & MIPT_LEAF_BIT)) {
+                uint32_t cs = (i == mate) ? slot + 1 : 2u * (uint32_t)atomicAdd(&cc->lines, 1);
+                slotOf[code] = cs;
+                depthOf[code] = depth + 1;
+                code = cs;
+            }
+            words[12 + i] = code;
+        } else {
+            words[3 * i] = words[3 * i + 1] = words[3 * i + 2] = 0x0000FFFFu;    // min above max: no ray enters an unused child
+            words[12 + i] = MIPT_NO_NODE;
+        }
+    }
+    uint4* o = wide + (size_t)slot * 4;
+    o[0] = make_uint4(words[0], words[1], words[2], words[3]);
+    o[1] = make_uint4(words[4], words[5], words[6], words[7]);
+    o[2] = make_uint4(words[8], words[9], words[10], words[11]);
+    o[3] = make_uint4(words[12], words[13], words[14], words[15]);
+    atomicMax(&cc->maxDepth, depth + 1);
+    atomicAdd(&cc->numWide, 1);
+}
+
+__global__ void k_collapse_init(uint32_t* slotOf, int32_t* depthOf, CollapseCounters* cc)
+{
+    slotOf[0] = 0; depthOf[0] = 0;
+    cc->lines = 1; cc->maxDepth = 0; cc->numWide = 0; cc->pad = 0;
+}
+
+// levelEnd[d] = number of binary nodes of depth <= d
+static int collapse_to_wide(BvhResult* out, const std::vector<int32_t>& levelEnd, hipStream_t stream)
 {
     const int64_t oldSlots = out->numNodeSlots;
     if (oldSlots <= 0 || (out->rootCode & MIPT_LEAF_BIT)) { out->numInner = 0; out->maxDepth = 0; return MIPT_OK; }
-    std::vector<uint32_t> src((size_t)oldSlots * 8);
-    if (hipMemcpyAsync(src.data(), out->nodes, src.size() * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIPT_E_DEVICE;
-    if (hipStreamSynchronize(stream) != hipSuccess) return MIPT_E_DEVICE;
-
-    struct Wide { WChild k[MIPT_NODE_WIDTH]; int n; };
-    auto make_wide = [&](uint32_t x) {
-        Wide W; W.n = 2;
-        for (int c = 0; c < 2; c++) {
-            W.k[c].code = src[(size_t)x * 8 + 6 + c];
-            for (int a = 0; a < 3; a++) W.k[c].w[a] = src[(size_t)x * 8 + 3 * c + a];
+    const int64_t inner2 = (oldSlots - 1) / 2;
+    const int64_t capSlots = 2 * (inner2 + 1);          // every wide node alone in its line: cannot be exceeded
+    uint32_t* slotOf = nullptr; int32_t* depthOf = nullptr; uint4* wide = nullptr; CollapseCounters* cc = nullptr;
+    CollapseCounters h = {};
+    int rc = MIPT_OK;
+    hipError_t e = hipSuccess;
+    auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    tryq(hipMalloc(&slotOf, 4 * (size_t)oldSlots)); tryq(hipMalloc(&depthOf, 4 * (size_t)oldSlots));
+    tryq(hipMalloc(&wide, 64 * (size_t)capSlots)); tryq(hipMalloc(&cc, sizeof(CollapseCounters)));
+    if (e == hipSuccess) {
+        tryq(hipMemsetAsync(slotOf, 0xFF, 4 * (size_t)oldSlots, stream));
+        tryq(hipMemsetAsync(wide, 0, 64 * (size_t)capSlots, stream));
+        hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(1), 0, stream, slotOf, depthOf, cc);
+        int32_t first = 0;
+        for (size_t d = 0; d < levelEnd.size(); d++) {
+            int32_t last = levelEnd[d];
+            if (last > first)
+                hipLaunchKernelGGL(k_collapse_level, dim3((unsigned)((last - first + 255) / 256)), dim3(256), 0, stream, out->nodes, first, last,
+                                   slotOf, depthOf, out->qcell[0], out->qcell[1], out->qcell[2], wide, cc);
+            first = last;
         }
-        while (W.n < MIPT_NODE_WIDTH) {
-            int best = -1; double bestArea = -1.0;
-            for (int i = 0; i < W.n; i++) {
-                if (W.k[i].code & MIPT_LEAF_BIT) continue;
-                double ar = wchild_area(W.k[i], out->qcell);
-                if (ar > bestArea) { bestArea = ar; best = i; }
-            }
-            if (best < 0) break;
-            uint32_t y = W.k[best].code;
-            for (int c = 0; c < 2; c++) {
-                WChild& d = (c == 0) ? W.k[best] : W.k[W.n];
-                d.code = src[(size_t)y * 8 + 6 + c];
-                for (int a = 0; a < 3; a++) d.w[a] = src[(size_t)y * 8 + 3 * c + a];
-            }
-            W.n++;
-        }
-        return W;
-    };
-
-    std::vector<uint32_t> slotOf((size_t)oldSlots, MIPT_NO_NODE);
-    std::vector<Wide> wide;                       // by slot; n = 0 marks an unused slot
-    struct Pending { uint32_t node; int32_t depth; };
-    std::vector<Pending> roots{ { 0u, 0 } };
-    int32_t maxDepth = 0; int64_t numWide = 0;
-    for (size_t head = 0; head < roots.size(); head++) {
-        const Pending r = roots[head];
-        slotOf[r.node] = (uint32_t)wide.size();
-        wide.push_back(make_wide(r.node)); numWide++;
-        const Wide W = wide.back();
-        if (r.depth + 1 > maxDepth) maxDepth = r.depth + 1;
-        int mate = -1; double mateArea = -1.0;
-        for (int i = 0; i < W.n; i++) {
-            if (W.k[i].code & MIPT_LEAF_BIT) continue;
-            double ar = wchild_area(W.k[i], out->qcell);
-            if (ar > mateArea) { mateArea = ar; mate = i; }
-        }
-        for (int i = 0; i < W.n; i++)
-            if (!(W.k[i].code & MIPT_LEAF_BIT) && i != mate) roots.push_back({ W.k[i].code, r.depth + 1 });
-        if (mate >= 0) {
-            uint32_t y = W.k[mate].code;
-            slotOf[y] = (uint32_t)wide.size();
-            wide.push_back(make_wide(y)); numWide++;
-            const Wide M = wide.back();
-            if (r.depth + 2 > maxDepth) maxDepth = r.depth + 2;
-            for (int i = 0; i < M.n; i++)
-                if (!(M.k[i].code & MIPT_LEAF_BIT)) roots.push_back({ M.k[i].code, r.depth + 2 });
-        } else {
-            Wide E; E.n = 0; wide.push_back(E);
+        tryq(hipMemcpyAsync(&h, cc, sizeof(h), hipMemcpyDeviceToHost, stream));
+        tryq(hipStreamSynchronize(stream));
+        tryq(hipGetLastError());
+    }
+    if (e == hipSuccess) {
+        const int64_t used = 2 * (int64_t)h.lines;
+        uint4* fit = nullptr;
+        if (used < capSlots && hipMalloc(&fit, 64 * (size_t)used) == hipSuccess) {      // give the unused tail back
+            tryq(hipMemcpy(fit, wide, 64 * (size_t)used, hipMemcpyDeviceToDevice));
+            (void)hipFree(wide);
+            wide = fit;
         }
     }
-    std::vector<uint32_t> dst(wide.size() * 16, 0u);
-    for (size_t i = 0; i < wide.size(); i++) {
-        const Wide& W = wide[i];
-        if (W.n == 0) continue;
-        for (int k = 0; k < MIPT_NODE_WIDTH; k++) {
-            uint32_t* boxw = &dst[i * 16 + 3 * k];
-            if (k < W.n) {
-                boxw[0] = W.k[k].w[0]; boxw[1] = W.k[k].w[1]; boxw[2] = W.k[k].w[2];
-                uint32_t code = W.k[k].code;
-                dst[i * 16 + 12 + k] = (code & MIPT_LEAF_BIT) ? code : slotOf[code];
-            } else {
-                boxw[0] = boxw[1] = boxw[2] = 0x0000FFFFu;     // min above max: no ray enters an unused child
-                dst[i * 16 + 12 + k] = MIPT_NO_NODE;
-            }
-        }
+    if (e == hipSuccess) {
+        (void)hipFree(out->nodes);
+        out->nodes = wide; wide = nullptr;
+        out->numNodeSlots = 2 * (int64_t)h.lines;
+        out->numInner = h.numWide;
+        out->maxDepth = h.maxDepth;
+    } else {
+        fprintf(stderr, "bvh build: collapse failed: %s\n", hipGetErrorString(e));
+        rc = MIPT_E_DEVICE;
     }
-    uint4* nn = nullptr;
-    if (hipMalloc(&nn, dst.size() * 4) != hipSuccess) return MIPT_E_DEVICE;
-    if (hipMemcpy(nn, dst.data(), dst.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(nn); return MIPT_E_DEVICE; }
-    (void)hipFree(out->nodes);
-    out->nodes = nn;
-    out->numNodeSlots = (int64_t)wide.size();
-    out->numInner = numWide;
-    out->maxDepth = maxDepth;
-    return MIPT_OK;
+    if (slotOf) (void)hipFree(slotOf);
+    if (depthOf) (void)hipFree(depthOf);
+    if (wide) (void)hipFree(wide);
+    if (cc) (void)hipFree(cc);
+    return rc;
 }
 
 void mipt_free_bvh(BvhResult* r)
@@ -468,6 +655,7 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     const int64_t maxNodes = 2 * (int64_t)n + 2;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     BuildCounters h = {};
+    std::vector<int32_t> levelEnd{ 1 };            // levelEnd[d] = number of nodes of depth <= d
     BNode rootH;
     int cur = 0, numActive = 0;
     const unsigned gridN = (unsigned)((n + 255) / 256);
@@ -497,7 +685,7 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
             HIPCHK(hipMalloc(&bins, sizeof(Bin) * (size_t)binCap));
         }
         hipLaunchKernelGGL(k_clear_bins, dim3((unsigned)((needBins + 255) / 256)), dim3(256), 0, stream, bins, needBins);
-        hipLaunchKernelGGL(k_bin, dim3(gridN), dim3(256), 0, stream, primIdx[cur], posNode[cur], nodes, primMin, primMax, bins, n, nb);
+        hipLaunchKernelGGL(k_bin, dim3((unsigned)((n + BIN_CHUNK - 1) / BIN_CHUNK)), dim3(256), 0, stream, primIdx[cur], posNode[cur], nodes, primMin, primMax, bins, n, nb);
         hipLaunchKernelGGL(k_split, dim3((unsigned)((numActive + 63) / 64)), dim3(64), 0, stream, nodes, active[cur], numActive, bins, nb,
                            maxLeaf, travCost, ctr, active[cur ^ 1]);
         hipLaunchKernelGGL(k_partition, dim3(gridN), dim3(256), 0, stream, primIdx[cur], posNode[cur], primIdx[cur ^ 1], posNode[cur ^ 1],
@@ -506,6 +694,7 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         HIPCHK(hipStreamSynchronize(stream));
         numActive = h.nextActive;
         if (h.nodeCount > maxNodes) { rc = MIPT_E_LIMIT; goto done; }
+        levelEnd.push_back(h.nodeCount);
         HIPCHK(hipMemsetAsync(&ctr->nextActive, 0, sizeof(int32_t), stream));
         cur ^= 1;
     }
@@ -555,9 +744,11 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     }
     {
         auto t0 = std::chrono::steady_clock::now();
-        rc = collapse_to_wide(out, stream);
+        rc = collapse_to_wide(out, levelEnd, stream);
         if (rc) goto done;
-        out->buildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        float hostMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (getenv("MIPT_BUILD_VERBOSE")) fprintf(stderr, "bvh build: %d triangles, device %.2f ms, collapse to wide nodes %.2f ms\n", n, (float)out->buildMs, hostMs);
+        out->buildMs += hostMs;
     }
 done:
     if (primMin) (void)hipFree(primMin);
