@@ -12,6 +12,8 @@
 #include <string.h>
 #include <string>
 #include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -114,14 +116,55 @@ void mipt_scene_destroy(mipt_scene* s)
     delete s;
 }
 
-// true if every float of a texel array is an integer in 0..255 (then 4 bytes per texel lose nothing)
-static bool texels_are_bytes(const float* f, size_t n)
+// Packs a run of float3 texels into BGRA8 words; false if a value is not an integer in 0..255
+// (then 4 bytes per texel would lose something and the texture stays float).
+static bool pack_byte_texels(const float* f, size_t count, uint32_t* dst)
 {
-    for (size_t i = 0; i < n; i++) {
-        float v = f[i];
-        if (!(v >= 0.0f && v <= 255.0f) || v != (float)(int)v) return false;
+    for (size_t i = 0; i < count; i++) {
+        float b = f[3 * i], g = f[3 * i + 1], r = f[3 * i + 2];
+        if (!(b >= 0.0f && b <= 255.0f) || b != (float)(int)b || !(g >= 0.0f && g <= 255.0f) || g != (float)(int)g ||
+            !(r >= 0.0f && r <= 255.0f) || r != (float)(int)r) return false;
+        dst[i] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | (255u << 24);
     }
     return true;
+}
+
+// One texture of the scene descriptor on its way into the texel pools.
+struct TexJob {
+    const void* data; int32_t fmt; size_t count; uint64_t off8;
+    std::atomic<int> notBytes{ 0 };
+    TexJob(const void* d, int32_t f, size_t c, uint64_t o) : data(d), fmt(f), count(c), off8(o) {}
+};
+
+// Fills pool8 from all jobs with a few host threads (the Crytek texture set is 67 M texels, 800 MB
+// as float3: one thread takes a third of a second over it).
+static void run_tex_jobs(std::vector<std::unique_ptr<TexJob>>& jobs, uint32_t* pool8)
+{
+    const size_t PIECE = 1u << 18;
+    struct Piece { TexJob* job; size_t first, count; };
+    std::vector<Piece> pieces;
+    for (auto& j : jobs)
+        for (size_t f = 0; f < j->count; f += PIECE) pieces.push_back({ j.get(), f, j->count - f < PIECE ? j->count - f : PIECE });
+    std::atomic<size_t> next{ 0 };
+    auto work = [&]() {
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= pieces.size()) return;
+            const Piece& p = pieces[i];
+            uint32_t* dst = pool8 + p.job->off8 + p.first;
+            if (p.job->fmt == MIPT_TEX_BGRA8) memcpy(dst, (const uint32_t*)p.job->data + p.first, 4 * p.count);
+            else if (!p.job->notBytes.load(std::memory_order_relaxed) && !pack_byte_texels((const float*)p.job->data + 3 * p.first, p.count, dst))
+                p.job->notBytes.store(1, std::memory_order_relaxed);
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? hw : 4;
+    if (nt > 16) nt = 16;
+    if (nt > pieces.size()) nt = pieces.size();
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
 }
 
 int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt, mipt_scene** out)
@@ -161,34 +204,20 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     // materials: byte-valued float texels are repacked to 4 bytes per texel (the reference
     // uploads 12, PathTracer.cu:599-618); anything else stays float
     std::vector<DevMaterial> mats((size_t)desc->num_materials);
-    std::vector<uint32_t> pool8; std::vector<float> poolF;
+    std::vector<float> poolF;
+    std::vector<std::unique_ptr<TexJob>> jobs;
+    struct Slot { uint64_t* off; int32_t* w; int32_t* h; int32_t* fmt; int job; };
+    std::vector<Slot> slots;
+    uint64_t pool8Count = 0;
     auto addTex = [&](const void* data, int32_t w, int32_t h, int32_t fmt, uint64_t& off, int32_t& dw, int32_t& dh, int32_t& dfmt) -> int {
         off = 0; dw = dh = 0; dfmt = MIPT_TEXFMT_NONE;
         if (!data || fmt == MIPT_TEX_NONE || w <= 0 || h <= 0) return MIPT_OK;
+        if (fmt != MIPT_TEX_BGRA8 && fmt != MIPT_TEX_F32X3) return MIPT_E_INVALID;
         size_t cnt = (size_t)w * (size_t)h;
-        if (fmt == MIPT_TEX_BGRA8) {
-            off = pool8.size();
-            const uint32_t* p = (const uint32_t*)data;
-            pool8.insert(pool8.end(), p, p + cnt);
-            dfmt = MIPT_TEXFMT_U8;
-        } else if (fmt == MIPT_TEX_F32X3) {
-            const float* f = (const float*)data;
-            if (texels_are_bytes(f, cnt * 3)) {
-                off = pool8.size();
-                pool8.resize(pool8.size() + cnt);
-                uint32_t* dst = pool8.data() + off;
-                for (size_t i = 0; i < cnt; i++)
-                    dst[i] = (uint32_t)f[3 * i] | ((uint32_t)f[3 * i + 1] << 8) | ((uint32_t)f[3 * i + 2] << 16) | (255u << 24);
-                dfmt = MIPT_TEXFMT_U8;
-            } else {
-                off = poolF.size();
-                poolF.insert(poolF.end(), f, f + cnt * 3);
-                dfmt = MIPT_TEXFMT_F32;
-            }
-        } else {
-            return MIPT_E_INVALID;
-        }
-        dw = w; dh = h;
+        slots.push_back({ &off, &dw, &dh, &dfmt, (int)jobs.size() });
+        jobs.emplace_back(new TexJob(data, fmt, cnt, pool8Count));
+        off = pool8Count; dw = w; dh = h; dfmt = MIPT_TEXFMT_U8;
+        pool8Count += cnt;
         return MIPT_OK;
     };
     for (int32_t i = 0; i < desc->num_materials; i++) {
@@ -199,6 +228,16 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
             addTex(m.nml_data, m.nml_width, m.nml_height, m.nml_format, d.nmlOffset, d.nmlW, d.nmlH, d.nmlFmt))
             return fail(MIPT_E_INVALID, "material %d has an unknown texel format", i);
         d.diffuse[0] = m.diffuse[0]; d.diffuse[1] = m.diffuse[1]; d.diffuse[2] = m.diffuse[2];
+    }
+    std::unique_ptr<uint32_t[]> pool8(pool8Count ? new uint32_t[pool8Count] : nullptr);
+    if (pool8Count) run_tex_jobs(jobs, pool8.get());
+    for (const Slot& sl : slots) {          // a texture with other values than bytes stays float (its place in the byte pool is left unused)
+        TexJob& j = *jobs[(size_t)sl.job];
+        if (!j.notBytes.load()) continue;
+        *sl.off = poolF.size();
+        const float* f = (const float*)j.data;
+        poolF.insert(poolF.end(), f, f + j.count * 3);
+        *sl.fmt = MIPT_TEXFMT_F32;
     }
 
     mipt_scene* s = new mipt_scene();
@@ -215,15 +254,15 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
         SCTRY(hipMalloc(&s->mats, sizeof(DevMaterial) * mats.size()));
         SCTRY(hipMemcpy(s->mats, mats.data(), sizeof(DevMaterial) * mats.size(), hipMemcpyHostToDevice));
     }
-    if (!pool8.empty()) {
-        SCTRY(hipMalloc(&s->texels, 4 * pool8.size()));
-        SCTRY(hipMemcpy(s->texels, pool8.data(), 4 * pool8.size(), hipMemcpyHostToDevice));
+    if (pool8Count) {
+        SCTRY(hipMalloc(&s->texels, 4 * (size_t)pool8Count));
+        SCTRY(hipMemcpy(s->texels, pool8.get(), 4 * (size_t)pool8Count, hipMemcpyHostToDevice));
     }
     if (!poolF.empty()) {
         SCTRY(hipMalloc(&s->texelsF, 4 * poolF.size()));
         SCTRY(hipMemcpy(s->texelsF, poolF.data(), 4 * poolF.size(), hipMemcpyHostToDevice));
     }
-    s->textureBytes = (int64_t)(4 * pool8.size() + 4 * poolF.size());
+    s->textureBytes = (int64_t)(4 * (size_t)pool8Count + 4 * poolF.size());
     s->uploadMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);

@@ -8,7 +8,9 @@
 #include "../../include/PTProgress.h"
 #include "../../include/mipt.h"
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -24,6 +26,9 @@ void CCUDAPathTracer::CalcRays(CPTCallback* pCallback, float3* pOutputImage, lon
 	float3 nSunPos, float3 /*nSunDir: unused by the reference kernel too*/, float nSunIntensity, bool bGlobalIllumination, bool bUseTextures, bool bUseNormals, CUDAMesh* pVB, long nNumMeshs, CUDAMaterial* pTextures, long nNumTextures)
 {
 	static_assert(sizeof(CCUDAVertex) == sizeof(mipt_vertex), "vertex layouts must match");
+	using clk = std::chrono::steady_clock;
+	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	const clk::time_point t0 = clk::now();
 	std::vector<mipt_material> mats((size_t)nNumTextures);
 	for (long i = 0; i < nNumTextures; i++) {
 		mipt_material& m = mats[(size_t)i];
@@ -75,16 +80,26 @@ void CCUDAPathTracer::CalcRays(CPTCallback* pCallback, float3* pOutputImage, lon
 	prm.shard_count = 1;
 
 	mipt_scene* scene = nullptr;
+	const clk::time_point t1 = clk::now();
 	if (mipt_init(0) != MIPT_OK) {     // the reference renders on device 0 (PathTracer.cu:577)
 		fprintf(stderr, "mipt_init failed: %s\n", mipt_last_error());
 		return;
 	}
+	const clk::time_point t2 = clk::now();
 	if (mipt_scene_create(&desc, nullptr, &scene) != MIPT_OK) {
 		fprintf(stderr, "mipt_scene_create failed: %s\n", mipt_last_error());
 		return;
 	}
+	const clk::time_point t3 = clk::now();
 	ProgressThunk thunk{ pCallback };
 	if (mipt_render(scene, &cam, &prm, (float*)pOutputImage, nullptr, nullptr, pCallback ? ProgressTrampoline : nullptr, &thunk) != MIPT_OK)
 		fprintf(stderr, "mipt_render failed: %s\n", mipt_last_error());
+	const clk::time_point t4 = clk::now();
+	if (getenv("MIPT_VERBOSE")) {
+		mipt_scene_info inf = {};
+		mipt_scene_get_info(scene, &inf);
+		fprintf(stderr, "CalcRays: flatten %.1f ms, device init %.1f ms, scene %.1f ms (upload %.1f, BVH build %.1f), render %.1f ms\n",
+		        ms(t0, t1), ms(t1, t2), ms(t2, t3), inf.upload_ms, inf.build_ms, ms(t3, t4));
+	}
 	mipt_scene_destroy(scene);
 }
