@@ -77,8 +77,9 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // as soon as they fall idle.
 //
 // Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  A loop iteration is
-// either ONE triangle step for the lanes that wait at a triangle (taken when `triVote` lanes wait
-// there or no lane is at an inner node), or a tight loop of node steps that runs until `nodeDrop`
+// either a short run of triangle steps for the lanes that wait at a triangle (taken when `triVote`
+// lanes wait there or no lane is at an inner node; repeated while more than `triStay` eighths of
+// them are still at a leaf), or a tight loop of node steps that runs until `nodeDrop`
 // of the lanes that entered it have left for a leaf or finished.  Lanes of the other kind sit the
 // phase out.  A node step fetches one 64-byte node (one cache line per lane), tests its four
 // child boxes, sorts the children that were hit by entry distance, continues with the nearest
@@ -91,7 +92,8 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
 #define TRACE_TRI_VOTE 16
-#define TRACE_NODE_DROP 32
+#define TRACE_NODE_DROP 40
+#define TRACE_TRI_STAY 2      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
 #define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
 
@@ -125,7 +127,7 @@ template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop)
+                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
@@ -198,28 +200,32 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_PROFILE
             pTriIters++;
 #endif
-            if ((int32_t)cur < 0) {
-                uint32_t slot = cur & ~MIPT_LEAF_BIT;
-                const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
-                float4 a = tr[0], b = tr[1], c = tr[2];
-                triCount++;
-                float t, u, v;
-                bool occluded = false;
-                if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
-                    int32_t id = (int32_t)__float_as_uint(a.w);
-                    if (MODE != 0) {
-                        if (t < FLT_MAX) { best.t = t; best.tri = id; occluded = true; }
-                    } else if (t < best.t || (t == best.t && id < best.tri)) {
-                        best.t = t; best.u = u; best.v = v; best.tri = id;
-                        tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+            // further triangle steps follow at once while enough of the lanes that entered are still at a leaf
+            const int triKeep = (__popcll(triMask) * triStay) >> 3;
+            do {
+                if ((int32_t)cur < 0) {
+                    uint32_t slot = cur & ~MIPT_LEAF_BIT;
+                    const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
+                    float4 a = tr[0], b = tr[1], c = tr[2];
+                    triCount++;
+                    float t, u, v;
+                    bool occluded = false;
+                    if (ray_triangle(o, d, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v)) {
+                        int32_t id = (int32_t)__float_as_uint(a.w);
+                        if (MODE != 0) {
+                            if (t < FLT_MAX) { best.t = t; best.tri = id; occluded = true; }
+                        } else if (t < best.t || (t == best.t && id < best.tri)) {
+                            best.t = t; best.u = u; best.v = v; best.tri = id;
+                            tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+                        }
                     }
+                    bool last = __float_as_uint(b.w) != 0 || slot + 1 >= (uint32_t)S.numTris;
+                    if (occluded) { cur = LANE_FINISHED; }
+                    else if (!last) { cur = cur + 1; }
+                    else if (sp > 0) { sp--; cur = stack_load(stack, spill, ldsCap, sp); }
+                    else { cur = LANE_FINISHED; }
                 }
-                bool last = __float_as_uint(b.w) != 0 || slot + 1 >= (uint32_t)S.numTris;
-                if (occluded) { cur = LANE_FINISHED; }
-                else if (!last) { cur = cur + 1; }
-                else if (sp > 0) { sp--; cur = stack_load(stack, spill, ldsCap, sp); }
-                else { cur = LANE_FINISHED; }
-            }
+            } while (triStay > 0 && __popcll(__ballot((int32_t)cur < 0)) > triKeep);
         } else {
             // ---- node steps, in a tight loop, until `triVote` lanes wait at a leaf or have finished
             int stay = __popcll(nodeMask) - nodeDrop;
@@ -314,6 +320,13 @@ static int trace_node_drop()
     return v;
 }
 
+static int trace_tri_stay()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MIPT_TRACE_TRI_STAY"); v = e ? atoi(e) : TRACE_TRI_STAY; if (v < 0) v = 0; if (v > 8) v = 8; }
+    return v;
+}
+
 static int trace_chunk()
 {
     static int v = -1;
@@ -345,7 +358,7 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
@@ -353,14 +366,14 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop());
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
 }
 
 // ---------------------------------------------------------------------------------------
