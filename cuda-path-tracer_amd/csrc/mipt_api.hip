@@ -34,6 +34,7 @@ struct mipt_scene {
     BvhResult bvh;
     float4* attr = nullptr;
     int32_t* triMat = nullptr;
+    float4* shade = nullptr;
     DevMaterial* mats = nullptr;
     uint32_t* texels = nullptr;
     float* texelsF = nullptr;
@@ -108,6 +109,7 @@ void mipt_scene_destroy(mipt_scene* s)
     mipt_free_bvh(&s->bvh);
     if (s->attr) (void)hipFree(s->attr);
     if (s->triMat) (void)hipFree(s->triMat);
+    if (s->shade) (void)hipFree(s->shade);
     if (s->mats) (void)hipFree(s->mats);
     if (s->texels) (void)hipFree(s->texels);
     if (s->texelsF) (void)hipFree(s->texelsF);
@@ -267,11 +269,20 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
 
     rc = mipt_build_bvh(s->attr, n, opt, s->stream, &s->bvh);
     if (rc) { mipt_scene_destroy(s); return fail(rc, "BVH build failed"); }
-    s->geometryBytes = (int64_t)(sizeof(mipt_vertex) * 3 * (size_t)n + 4 * (size_t)n + 16 * MIPT_NODE_WIDTH * (size_t)s->bvh.numNodeSlots + 16 * MIPT_TRI_F4 * (size_t)s->bvh.numLeafSlots);
+    s->geometryBytes = (int64_t)(16 * MIPT_SHADE_F4 * (size_t)n + 16 * MIPT_NODE_WIDTH * (size_t)s->bvh.numNodeSlots + 16 * MIPT_TRI_F4 * (size_t)s->bvh.numLeafSlots);
 
     DevScene& D = s->dev;
     D.nodes = s->bvh.nodes; D.tris = s->bvh.tris;
-    D.attr = s->attr; D.triMat = s->triMat; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
+    if (n > 0) {
+        // per-triangle shading records; the corner arrays are only needed to make them and the BVH
+        SCTRY(hipMalloc(&s->shade, sizeof(float4) * MIPT_SHADE_F4 * (size_t)n));
+        launch_make_shading(s->attr, s->triMat, n, s->shade, s->stream);
+        SCTRY(hipStreamSynchronize(s->stream));
+        SCTRY(hipGetLastError());
+        (void)hipFree(s->attr); s->attr = nullptr;
+        (void)hipFree(s->triMat); s->triMat = nullptr;
+    }
+    D.shade = s->shade; D.mats = s->mats; D.texels = s->texels; D.texelsF = s->texelsF;
     for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
     // depth-first walk of a tree whose nodes push up to (width - 1) siblings per level
@@ -550,7 +561,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     int32_t* nextCount = (level < 3) ? C + 4 * level : nullptr;
                     RayQueue cur = f->q[(level - 1) & 1], nxt = f->q[level & 1];
                     spanBegin(0);
-                    launch_closest(S, cur, Lc + 0, (int32_t)slots, Lc + 1, f->hit, R.eps, f->stats, g_numCUs, st);
+                    launch_closest(S, cur, Lc + 0, (int32_t)slots, Lc + 1, f->hit, R.eps, f->stats, g_numCUs, st, true);
                     spanEnd();
                     launch_shade_bounce(S, R, cur, f->hit, Lc + 0, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
                                         f->shadowQ, Lc + 2, nxt, nextCount, st);

@@ -25,6 +25,7 @@
 #endif
 #define MIPT_NODE_WIDTH 4
 #define MIPT_STACK_LDS_MAX 22   // stack entries per lane kept in LDS (5.5 KiB per wave: 28 waves per compute unit)
+#define MIPT_SHADE_F4 5
 #define MIPT_LEAF_BIT 0x80000000u
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
@@ -44,8 +45,7 @@ struct DevMaterial {
 struct DevScene {
     const uint4*       nodes;
     const float4*      tris;       // MIPT_TRI_F4 float4 per leaf slot
-    const float4*      attr;       // 6 float4 per global triangle: three (pos3, normal3, uv2) corners
-    const int32_t*     triMat;     // material per global triangle, -1 = none
+    const float4*      shade;      // MIPT_SHADE_F4 float4 per global triangle, see k_make_shading
     const DevMaterial* mats;
     const uint32_t*    texels;
     const float*       texelsF;
@@ -109,8 +109,9 @@ struct RayQueue {
 
 void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s);
 // closest-hit over q[0 .. *d_count): hit[i] = (t, ua, va, bits triangle id or -1)
+void launch_make_shading(const float4* attr, const int32_t* triMat, int64_t n, float4* shade, hipStream_t s);
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
-                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s);
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit = false);
 // any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,

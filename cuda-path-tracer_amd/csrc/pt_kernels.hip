@@ -127,7 +127,7 @@ template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay)
+                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagInHit)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         if (cur == LANE_FINISHED) {
             bool found = best.tri >= 0;
             if (MODE == 0) {
-                hit[rayIdx] = make_float4(best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
+                // the shading kernels do not use the distance: with tagInHit the ray's slot id travels in its place
+                hit[rayIdx] = make_float4(tagInHit ? __int_as_float(tag0) : best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
             } else if (MODE == 1) {
                 if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
                     if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
@@ -354,11 +355,11 @@ static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
 }
 
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
-                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit)
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0);
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
@@ -366,14 +367,47 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
     hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay());
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Shading record of a triangle, MIPT_SHADE_F4 float4 in a row so that a hit gathers one short run
+// of memory: the three positions, the material, the flat normal of CMesh::Intersect
+// (CPUPathTracer.cpp:236-243: normalised mean of the corner normals, the same for every hit of
+// the triangle) and the corner texture coordinates.
+//   [0] = (p0, bits material)  [1] = (p1, N.x)  [2] = (p2, N.y)  [3] = (t0.x, t0.y, t1.x, t1.y)  [4] = (t2.x, t2.y, N.z, 0)
+// attr holds the corners as the caller gave them: 2 float4 each = (pos3, normal3, tex2).
+__global__ void __launch_bounds__(256) k_make_shading(const float4* __restrict__ attr, const int32_t* __restrict__ triMat,
+                                                     int64_t n, float4* shade)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* a = attr + (size_t)i * 6;
+    float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+    // corner k: pos = (a[2k].x, a[2k].y, a[2k].z), normal = (a[2k].w, a[2k+1].x, a[2k+1].y), tex = (a[2k+1].z, a[2k+1].w)
+    F3 nn;
+    nn.x = (a0.w + a2.w + a4.w) / 3;
+    nn.y = (a1.x + a3.x + a5.x) / 3;
+    nn.z = (a1.y + a3.y + a5.y) / 3;
+    F3 N = f3normalize(nn);
+    float4* o = shade + (size_t)i * MIPT_SHADE_F4;
+    o[0] = make_float4(a0.x, a0.y, a0.z, __int_as_float(triMat[i]));
+    o[1] = make_float4(a2.x, a2.y, a2.z, N.x);
+    o[2] = make_float4(a4.x, a4.y, a4.z, N.y);
+    o[3] = make_float4(a1.z, a1.w, a3.z, a3.w);
+    o[4] = make_float4(a5.z, a5.w, N.z, 0.0f);
+}
+void launch_make_shading(const float4* attr, const int32_t* triMat, int64_t n, float4* shade, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_make_shading, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, attr, triMat, n, shade);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -402,22 +436,17 @@ __device__ __forceinline__ uint32_t fetch_texel_bgr(const DevScene& S, int fmt, 
 __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender& R, int tri, float ua, float va)
 {
     Surface sf;
-    const float4* a = S.attr + (size_t)tri * 6;
-    float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
-    // corner k: pos = (a[2k].x, a[2k].y, a[2k].z), normal = (a[2k].w, a[2k+1].x, a[2k+1].y), tex = (a[2k+1].z, a[2k+1].w)
+    const float4* a = S.shade + (size_t)tri * MIPT_SHADE_F4;
+    float4 r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4];
     float w = 1 - ua - va;
-    float u = w * a1.w + ua * a3.w + va * a5.w;          // :231 uses tex.y
-    float v = w * a1.z + ua * a3.z + va * a5.z;          // :232 uses tex.x
-    sf.hp.x = w * a0.x + ua * a2.x + va * a4.x;
-    sf.hp.y = w * a0.y + ua * a2.y + va * a4.y;
-    sf.hp.z = w * a0.z + ua * a2.z + va * a4.z;
-    F3 n;
-    n.x = (a0.w + a2.w + a4.w) / 3;
-    n.y = (a1.x + a3.x + a5.x) / 3;
-    n.z = (a1.y + a3.y + a5.y) / 3;
-    sf.N = f3normalize(n);
+    float u = w * r3.y + ua * r3.w + va * r4.y;          // :231 uses tex.y
+    float v = w * r3.x + ua * r3.z + va * r4.x;          // :232 uses tex.x
+    sf.hp.x = w * r0.x + ua * r1.x + va * r2.x;
+    sf.hp.y = w * r0.y + ua * r1.y + va * r2.y;
+    sf.hp.z = w * r0.z + ua * r1.z + va * r2.z;
+    sf.N = f3(r1.w, r2.w, r4.z);                        // normalised mean of the corner normals, :236-243, made once per triangle
 
-    int mi = S.triMat[tri];
+    int mi = __float_as_int(r0.w);
     F3 nmlMap = f3(0, 1, 0);
     long texW = 0, texH = 0, nmlW = 0, nmlH = 0;
     int texFmt = MIPT_TEXFMT_NONE, nmlFmt = MIPT_TEXFMT_NONE;
@@ -601,7 +630,7 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             int idx = running + prefix;
             running += __popcll(mask);
             if (isHit) {
-                int slot = __float_as_int(q.o[i].w);
+                int slot = __float_as_int(h.x);           // the traversal put the ray's slot id where the distance would be
                 Surface sf = surface_at(S, R, tri, h.y, h.z);
                 F3 so, sd;
                 float D = direct_term(R, sf, so, sd);
