@@ -117,10 +117,12 @@ __device__ __forceinline__ void order_pair(uint32_t& ka, uint32_t& ca, uint32_t&
     uint32_t cmin = swap ? cb : ca, cmax = swap ? ca : cb;
     ka = kmin; kb = kmax; ca = cmin; cb = cmax;
 }
-__device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull)
+__device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, int& hits)
 {
     float t;
-    return box_test(r, wx, wy, wz, tcull, t) ? __float_as_uint(t) : KEY_MISS;
+    bool h = box_test(r, wx, wy, wz, tcull, t);
+    hits += h;
+    return h ? __float_as_uint(t) : KEY_MISS;
 }
 
 template <int MODE>
@@ -242,8 +244,9 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
                     nodeCount++;
                     // entry distance per child, +inf where the ray misses the child's box
-                    uint32_t k0 = box_key(br, w0.x, w0.y, w0.z, tcull), k1 = box_key(br, w0.w, w1.x, w1.y, tcull);
-                    uint32_t k2 = box_key(br, w1.z, w1.w, w2.x, tcull), k3 = box_key(br, w2.y, w2.z, w2.w, tcull);
+                    int hits = 0;
+                    uint32_t k0 = box_key(br, w0.x, w0.y, w0.z, tcull, hits), k1 = box_key(br, w0.w, w1.x, w1.y, tcull, hits);
+                    uint32_t k2 = box_key(br, w1.z, w1.w, w2.x, tcull, hits), k3 = box_key(br, w2.y, w2.z, w2.w, tcull, hits);
                     uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
                     // nearest first: five compare-exchanges sort the four (distance, child) pairs
                     order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
@@ -254,7 +257,6 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     // child that was missed that offset is negative; taken modulo 4 it points above the
                     // new top of the stack, where the value is never read.  All three stores can thus be
                     // unconditional (the stack has three spare entries).
-                    int hits = (k0 != KEY_MISS) + (k1 != KEY_MISS) + (k2 != KEY_MISS) + (k3 != KEY_MISS);
                     int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
                     if (__ballot(sp + 3 >= ldsCap) == 0) {
                         stack[p1 * WAVE] = c1; stack[p2 * WAVE] = c2; stack[p3 * WAVE] = c3;
