@@ -76,14 +76,16 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
 // as soon as they fall idle.
 //
-// Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  A loop iteration is
-// either a short run of triangle steps for the lanes that wait at a triangle (taken when `triVote`
-// lanes wait there or no lane is at an inner node; repeated while more than `triStay` eighths of
-// them are still at a leaf), or a tight loop of node steps that runs until `nodeDrop`
-// of the lanes that entered it have left for a leaf or finished.  Lanes of the other kind sit the
-// phase out.  A node step fetches one 64-byte node (one cache line per lane), tests its four
-// child boxes, sorts the children that were hit by entry distance, continues with the nearest
-// and pushes the others.  Both thresholds were chosen by measurement (profiles/).
+// Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  One round of the
+// loop hands rays to idle lanes, then runs a phase and writes the results of finished rays.  The
+// node phase is a tight loop of node steps that ends when `nodeDrop` of the lanes that entered it
+// have left for a leaf or finished; the triangle phase is a short run of triangle steps for the
+// lanes that wait at a triangle, entered when `triVote` of them do or no lane is at an inner node
+// and repeated while more than `triStay` eighths of them are still at a leaf.  Lanes of the other
+// kind sit a phase out.  Closest-hit rounds run the node phase and then the triangle phase,
+// any-hit rounds one of the two.  A node step fetches one 64-byte node (one cache line per lane),
+// tests its four child boxes, sorts the children that were hit by entry distance, continues with
+// the nearest and pushes the others.  The thresholds were chosen by measurement (profiles/).
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
@@ -192,13 +194,59 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 rangeNext += (want < avail) ? want : avail;
             }
         }
-        const unsigned long long triMask = __ballot((int32_t)cur < 0), nodeMask = __ballot(cur < LANE_FINISHED);
+        unsigned long long triMask = __ballot((int32_t)cur < 0), nodeMask = __ballot(cur < LANE_FINISHED);
         if ((triMask | nodeMask) == 0 && __ballot(cur == LANE_FINISHED) == 0) {
             if (queueDry && rangeNext >= rangeEnd) break;
             continue;
         }
-        if (nodeMask == 0 || __popcll(triMask) >= triVote) {
-            // ---- triangle step: the exact triangle test on one triangle of the lane's leaf
+        // ---- node steps, in a tight loop, until `nodeDrop` of the lanes that entered have left
+        auto nodePhase = [&]() {
+            int stay = __popcll(nodeMask) - nodeDrop;
+            if (stay < 0) stay = 0;
+#ifdef MIPT_TRACE_PROFILE
+            pNodePhases++;
+#endif
+            do {
+#ifdef MIPT_TRACE_PROFILE
+                pNodeIters++;
+#endif
+                if (cur < LANE_FINISHED) {
+                    const uint4* nd = nodes + (size_t)cur * 4;
+                    uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+                    nodeCount++;
+                    // entry distance per child, +inf where the ray misses the child's box
+                    int hits = 0;
+                    uint32_t k0 = box_key(br, w0.x, w0.y, w0.z, tcull, hits), k1 = box_key(br, w0.w, w1.x, w1.y, tcull, hits);
+                    uint32_t k2 = box_key(br, w1.z, w1.w, w2.x, tcull, hits), k3 = box_key(br, w2.y, w2.z, w2.w, tcull, hits);
+                    uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
+                    // nearest first: five compare-exchanges sort the four (distance, child) pairs
+                    order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
+                    order_pair(k0, c0, k2, c2); order_pair(k1, c1, k3, c3);
+                    order_pair(k1, c1, k2, c2);
+                    // The children that were hit are the first `hits`; the nearest is visited now, the
+                    // others go on the stack, farthest deepest: child j lands at sp + hits - 1 - j.  For a
+                    // child that was missed that offset is negative; taken modulo 4 it points above the
+                    // new top of the stack, where the value is never read.  All three stores can thus be
+                    // unconditional (the stack has three spare entries).
+                    int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
+                    if (__builtin_expect(__ballot(sp + 3 >= ldsCap) == 0, 1)) {
+                        stack[p1 * WAVE] = c1; stack[p2 * WAVE] = c2; stack[p3 * WAVE] = c3;
+                    } else {
+                        stack_store(stack, spill, ldsCap, p1, c1); stack_store(stack, spill, ldsCap, p2, c2); stack_store(stack, spill, ldsCap, p3, c3);
+                    }
+                    if (hits > 0) {
+                        sp += hits - 1;
+                        cur = c0;
+                    } else if (sp > 0) {
+                        sp--; cur = stack_load(stack, spill, ldsCap, sp);
+                    } else {
+                        cur = LANE_FINISHED;
+                    }
+                }
+            } while (__popcll(__ballot(cur < LANE_FINISHED)) > stay);
+        };
+        // ---- triangle steps: the exact triangle test on one triangle of the lane's leaf
+        auto triPhase = [&]() {
 #ifdef MIPT_TRACE_PROFILE
             pTriIters++;
 #endif
@@ -228,51 +276,18 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     else { cur = LANE_FINISHED; }
                 }
             } while (triStay > 0 && __popcll(__ballot((int32_t)cur < 0)) > triKeep);
+        };
+        if (MODE == 0) {
+            // closest hit: the triangle phase follows the node phase in the same round
+            if (nodeMask != 0 && __popcll(triMask) < triVote) {
+                nodePhase();
+                triMask = __ballot((int32_t)cur < 0); nodeMask = __ballot(cur < LANE_FINISHED);
+            }
+            if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) triPhase();
         } else {
-            // ---- node steps, in a tight loop, until `triVote` lanes wait at a leaf or have finished
-            int stay = __popcll(nodeMask) - nodeDrop;
-            if (stay < 0) stay = 0;
-#ifdef MIPT_TRACE_PROFILE
-            pNodePhases++;
-#endif
-            do {
-#ifdef MIPT_TRACE_PROFILE
-                pNodeIters++;
-#endif
-                if (cur < LANE_FINISHED) {
-                    const uint4* nd = nodes + (size_t)cur * 4;
-                    uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
-                    nodeCount++;
-                    // entry distance per child, +inf where the ray misses the child's box
-                    int hits = 0;
-                    uint32_t k0 = box_key(br, w0.x, w0.y, w0.z, tcull, hits), k1 = box_key(br, w0.w, w1.x, w1.y, tcull, hits);
-                    uint32_t k2 = box_key(br, w1.z, w1.w, w2.x, tcull, hits), k3 = box_key(br, w2.y, w2.z, w2.w, tcull, hits);
-                    uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
-                    // nearest first: five compare-exchanges sort the four (distance, child) pairs
-                    order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
-                    order_pair(k0, c0, k2, c2); order_pair(k1, c1, k3, c3);
-                    order_pair(k1, c1, k2, c2);
-                    // The children that were hit are the first `hits`; the nearest is visited now, the
-                    // others go on the stack, farthest deepest: child j lands at sp + hits - 1 - j.  For a
-                    // child that was missed that offset is negative; taken modulo 4 it points above the
-                    // new top of the stack, where the value is never read.  All three stores can thus be
-                    // unconditional (the stack has three spare entries).
-                    int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
-                    if (__ballot(sp + 3 >= ldsCap) == 0) {
-                        stack[p1 * WAVE] = c1; stack[p2 * WAVE] = c2; stack[p3 * WAVE] = c3;
-                    } else {
-                        stack_store(stack, spill, ldsCap, p1, c1); stack_store(stack, spill, ldsCap, p2, c2); stack_store(stack, spill, ldsCap, p3, c3);
-                    }
-                    if (hits > 0) {
-                        sp += hits - 1;
-                        cur = c0;
-                    } else if (sp > 0) {
-                        sp--; cur = stack_load(stack, spill, ldsCap, sp);
-                    } else {
-                        cur = LANE_FINISHED;
-                    }
-                }
-            } while (__popcll(__ballot(cur < LANE_FINISHED)) > stay);
+            // any hit: one phase per round
+            if (nodeMask == 0 || __popcll(triMask) >= triVote) triPhase();
+            else nodePhase();
         }
 #ifdef MIPT_TRACE_PROFILE
         { unsigned long long fm = __ballot(cur == LANE_FINISHED); if (fm) { pFinish++; pFinishLanes += __popcll(fm); } }
