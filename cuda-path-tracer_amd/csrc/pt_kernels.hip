@@ -82,8 +82,7 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // have left for a leaf or finished; the triangle phase is a short run of triangle steps for the
 // lanes that wait at a triangle, entered when `triVote` of them do or no lane is at an inner node
 // and repeated while more than `triStay` eighths of them are still at a leaf.  Lanes of the other
-// kind sit a phase out.  Closest-hit rounds run the node phase and then the triangle phase,
-// any-hit rounds one of the two.  A node step fetches one 64-byte node (one cache line per lane),
+// kind sit a phase out.  A round runs the node phase and then the triangle phase.  A node step fetches one 64-byte node (one cache line per lane),
 // tests its four child boxes, sorts the children that were hit by entry distance, continues with
 // the nearest and pushes the others.  The thresholds were chosen by measurement (profiles/).
 //
@@ -277,18 +276,12 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 }
             } while (triStay > 0 && __popcll(__ballot((int32_t)cur < 0)) > triKeep);
         };
-        if (MODE == 0) {
-            // closest hit: the triangle phase follows the node phase in the same round
-            if (nodeMask != 0 && __popcll(triMask) < triVote) {
-                nodePhase();
-                triMask = __ballot((int32_t)cur < 0); nodeMask = __ballot(cur < LANE_FINISHED);
-            }
-            if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) triPhase();
-        } else {
-            // any hit: one phase per round
-            if (nodeMask == 0 || __popcll(triMask) >= triVote) triPhase();
-            else nodePhase();
+        // the triangle phase follows the node phase in the same round
+        if (nodeMask != 0 && __popcll(triMask) < triVote) {
+            nodePhase();
+            triMask = __ballot((int32_t)cur < 0); nodeMask = __ballot(cur < LANE_FINISHED);
         }
+        if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) triPhase();
 #ifdef MIPT_TRACE_PROFILE
         { unsigned long long fm = __ballot(cur == LANE_FINISHED); if (fm) { pFinish++; pFinishLanes += __popcll(fm); } }
 #endif
