@@ -201,3 +201,21 @@ def test_cancel_and_partial_image(gpu, cornell):
     fr.finalize(acc.ptr, out.ptr)
     ref, _, _ = sc.render(cam, prm)
     assert np.array_equal(out.to_host().reshape(135, 240, 3), ref)
+
+
+def test_size_limits_are_rejected_before_any_work(gpu, cornell):
+    """Sizes beyond what the library indexes with 31 bits come back as errors, not as faults."""
+    import ctypes as C
+    sc = gpu.Scene(cornell.desc)
+    # 2^31 rays: refused on the count alone (the array is never touched)
+    rays = np.zeros((1, 6), dtype=np.float32)
+    rc = gpu.lib().mipt_trace_rays(sc._h, rays.ctypes.data, (1 << 31) - 64, 1e-20, None, None, None)
+    assert rc == -4 and b"too many rays" in gpu.lib().mipt_last_error()
+    # 65536 x 32768 pixels
+    cam, sun = scenes.cornell_camera(div=1, width=65536, height=32768)
+    with pytest.raises(gpu.MiptError, match="too large"):
+        gpu.Frame(sc, cam, host.default_params(sun_pos=sun))
+    # more samples than the reference's dialog accepts are clamped to 10000 (RayTracerView.cpp:785-786), not an error
+    cam, sun = scenes.cornell_camera(div=120)
+    fr = gpu.Frame(sc, cam, host.default_params(sun_pos=sun, global_illumination=0, num_samples=1 << 30))
+    assert fr.num_pixels == 16 * 9
