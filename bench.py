@@ -106,12 +106,12 @@ def main():
     # MIPT_BENCH_BACKEND=gloo rehearses the multi-rank flow where the ranks have to share GPUs (the
     # sums then travel through host memory); the real run uses one GPU per rank and RCCL
     backend = os.environ.get("MIPT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)              # before the communicator is created: it binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
     device.init(local_rank)
     coll = "cuda" if backend == "nccl" else "cpu"      # where tensors handed to collectives live
 
@@ -208,6 +208,7 @@ def main():
                 "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
                 "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(args.workload),
+                "traffic_unit": "bytes per launch, fabric side of L2 (profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": bytes_ / launches,
                 "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
                 "triangle_tests_per_s": tot[1].item() / closest_s if closest_s > 0 else 0.0,
