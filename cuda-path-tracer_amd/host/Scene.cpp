@@ -73,8 +73,8 @@ HostScene* AssembleObjScene(const char* path, bool flipWinding)
 		t.name = m.name;
 		t.diffuse[0] = m.Kd[2]; t.diffuse[1] = m.Kd[1]; t.diffuse[2] = m.Kd[0];
 		if (!m.map_Kd.empty()) {
-			if (!LoadPng((dir + m.map_Kd).c_str(), t.tex, t.width, t.height)) continue;
-			if (!m.map_Bump.empty()) LoadPng((dir + m.map_Bump).c_str(), t.nml, t.nmlWidth, t.nmlHeight);
+			if (!LoadImageFile((dir + m.map_Kd).c_str(), t.tex, t.width, t.height)) continue;
+			if (!m.map_Bump.empty()) LoadImageFile((dir + m.map_Bump).c_str(), t.nml, t.nmlWidth, t.nmlHeight);
 		}
 		scene->materials.push_back(std::move(t));
 	}

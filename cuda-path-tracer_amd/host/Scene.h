@@ -58,5 +58,9 @@ HostScene* BuildInstanced(const HostScene& base, int copies, float spacing);
 
 // PNG (8-bit grey / RGB / RGBA / palette, 1-bit grey; non-interlaced) -> BGRA8 DWORDs
 bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
+// baseline JPEG (Jpeg.cpp); same texel layout
+bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
+// PNG or JPEG by the file's first bytes
+bool LoadImageFile(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
 
 } // namespace pth

@@ -148,6 +148,18 @@ int mipt_host_load_png(const char* path, uint32_t** out, int32_t* width, int32_t
 	return MIPT_OK;
 }
 
+int mipt_host_load_image(const char* path, uint32_t** out, int32_t* width, int32_t* height)
+{
+	std::vector<uint32_t> px; int32_t w = 0, h = 0;
+	if (!path || !out || !LoadImageFile(path, px, w, h)) return MIPT_E_INVALID;
+	*out = (uint32_t*)malloc(px.size() * 4);
+	if (!*out) return MIPT_E_NOMEM;
+	memcpy(*out, px.data(), px.size() * 4);
+	if (width) *width = w;
+	if (height) *height = h;
+	return MIPT_OK;
+}
+
 void mipt_host_free(void* p) { free(p); }
 
 } // extern "C"

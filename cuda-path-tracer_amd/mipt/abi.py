@@ -88,6 +88,6 @@ MIPT_SYMBOLS = [
 MIPT_HOST_SYMBOLS = [
     "mipt_host_scene_load_obj", "mipt_host_scene_atrium", "mipt_host_scene_instanced", "mipt_host_scene_free",
     "mipt_host_scene_desc", "mipt_host_scene_label", "mipt_host_camera_preset", "mipt_host_camera_make",
-    "mipt_host_default_params", "mipt_host_pack_bgra", "mipt_host_write_ppm", "mipt_host_load_png",
+    "mipt_host_default_params", "mipt_host_pack_bgra", "mipt_host_write_ppm", "mipt_host_load_png", "mipt_host_load_image",
     "mipt_host_free",
 ]

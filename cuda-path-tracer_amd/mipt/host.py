@@ -36,6 +36,7 @@ def lib():
         L.mipt_host_pack_bgra.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.mipt_host_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mipt_host_load_png.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.mipt_host_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mipt_host_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -135,9 +136,18 @@ def write_ppm(path, bgr255, width, height):
 
 
 def load_png(path):
+    return _load(lib().mipt_host_load_png, path)
+
+
+def load_image(path):
+    """PNG or baseline JPEG -> (h, w) uint32 BGRA8 texels."""
+    return _load(lib().mipt_host_load_image, path)
+
+
+def _load(fn, path):
     ptr = C.c_void_p()
     w, h = C.c_int32(), C.c_int32()
-    rc = lib().mipt_host_load_png(os.fsencode(path), C.byref(ptr), C.byref(w), C.byref(h))
+    rc = fn(os.fsencode(path), C.byref(ptr), C.byref(w), C.byref(h))
     if rc != 0:
         raise IOError(f"cannot decode {path}")
     arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(h.value, w.value)).copy()

@@ -29,7 +29,7 @@ typedef struct mipt_host_scene mipt_host_scene;
  * group, the first three vertices of each face, optional winding flip (Cornell box,
  * MainFrm.cpp:217,380-383), diffuse stored BGR, meshes ordered by triangle count
  * descending (a stable sort; the reference's std::sort is unstable).  Texture files
- * are decoded when they are PNG.  A material that names a diffuse texture which cannot
+ * are decoded when they are PNG or baseline JPEG.  A material that names a diffuse texture which cannot
  * be loaded is left out of the material table, as in MainFrm.cpp:258-262: meshes that use
  * it then have no material (index -1).  Returns NULL on failure. */
 mipt_host_scene* mipt_host_scene_load_obj(const char* path, int32_t flip_winding);
@@ -68,6 +68,10 @@ int mipt_host_write_ppm(const char* path, const float* bgr255, int32_t width, in
 /* Decodes a PNG file to BGRA8 DWORD texels (byte0 = blue), the layout MainFrm.cpp:262-269
  * produces through CImage.  *out is malloc'ed; release with mipt_host_free. */
 int mipt_host_load_png(const char* path, uint32_t** out, int32_t* width, int32_t* height);
+/* The same for a PNG or a baseline JPEG file, told apart by their first bytes (CImage::Load takes
+ * both, MainFrm.cpp:258; the default Sponza scene names JPEG textures).  Progressive JPEG files
+ * are refused. */
+int mipt_host_load_image(const char* path, uint32_t** out, int32_t* width, int32_t* height);
 void mipt_host_free(void* p);
 
 #ifdef __cplusplus

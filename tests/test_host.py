@@ -152,3 +152,64 @@ def test_shard_fields_and_tile_owner():
     assert owners == {0, 1, 2, 3}
     assert sharding.tile_owner(31, 31, 100, 4, 32) == 0 and sharding.tile_owner(32, 0, 100, 4, 32) == 1
     assert sharding.tile_owner(0, 32, 100, 4, 32) == 0                  # 4 tiles per row -> row 1 starts at tile 4
+
+
+def test_jpeg_decoder_against_libjpeg(tmp_path):
+    """Baseline JPEG files written by Pillow (libjpeg) decode to the same picture as Pillow's own
+    decoder gives, up to the rounding of a different inverse DCT; with subsampled chroma Pillow
+    interpolates where this decoder replicates, so only the luminance-dominated error is bounded.
+    The reference decodes through GDI+ (CImage, MainFrm.cpp:258): parity with it is unpinned."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:77, 0:101]
+    img = np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 40 + 2 * xx, 255 - 3 * yy], axis=2)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    cases = [("444.jpg", dict(quality=92, subsampling=0), 2, 0.6), ("420.jpg", dict(quality=85, subsampling=2), 40, 3.0),
+             ("422_restart.jpg", dict(quality=75, subsampling=1, restart_marker_blocks=3), 40, 3.0),
+             ("optimized.jpg", dict(quality=95, subsampling=0, optimize=True), 2, 0.6)]
+    for name, opts, max_err, mean_err in cases:
+        path = str(tmp_path / name)
+        try:
+            PIL.fromarray(img, "RGB").save(path, "JPEG", **opts)
+        except TypeError:
+            opts.pop("restart_marker_blocks", None)
+            PIL.fromarray(img, "RGB").save(path, "JPEG", **opts)
+        want = np.asarray(PIL.open(path).convert("RGB")).astype(np.int32)
+        tex = host.load_image(path)
+        assert tex.shape == (77, 101)
+        got = np.stack([(tex >> 16) & 255, (tex >> 8) & 255, tex & 255], axis=2).astype(np.int32)     # byte0 = blue
+        assert (tex >> 24 == 255).all()
+        err = np.abs(got - want)
+        assert err.max() <= max_err and err.mean() <= mean_err, (name, err.max(), err.mean())
+    # greyscale
+    path = str(tmp_path / "grey.jpg")
+    PIL.fromarray(img[:, :, 0], "L").save(path, "JPEG", quality=90)
+    want = np.asarray(PIL.open(path)).astype(np.int32)
+    tex = host.load_image(path)
+    assert np.abs((tex & 255).astype(np.int32) - want).max() <= 2 and ((tex & 255) == ((tex >> 8) & 255)).all()
+    # progressive files are refused, not misread
+    path = str(tmp_path / "prog.jpg")
+    PIL.fromarray(img, "RGB").save(path, "JPEG", quality=90, progressive=True)
+    with pytest.raises(IOError):
+        host.load_image(path)
+    # load_image also takes PNG
+    path = str(tmp_path / "a.png")
+    PIL.fromarray(img, "RGB").save(path, "PNG")
+    tex = host.load_image(path)
+    assert np.array_equal(np.stack([(tex >> 16) & 255, (tex >> 8) & 255, tex & 255], axis=2).astype(np.uint8), img)
+
+
+def test_obj_material_with_jpeg_texture(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    PIL.fromarray(np.full((4, 8, 3), (200, 100, 50), dtype=np.uint8), "RGB").save(str(tmp_path / "wall.jpg"), "JPEG", quality=95, subsampling=0)
+    (tmp_path / "m.mtl").write_text("newmtl wall\nKd 1 1 1\nmap_Kd wall.jpg\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\nusemtl wall\nf 1/1/1 2/2/1 3/3/1\n")
+    s = host.HostScene.load_obj(str(tmp_path / "m.obj"))
+    d = s.desc.contents
+    assert d.num_materials == 1
+    m = d.materials[0]
+    assert (m.tex_width, m.tex_height, m.tex_format) == (8, 4, abi.MIPT_TEX_BGRA8)
+    import ctypes as C
+    tex = np.ctypeslib.as_array(C.cast(m.tex_data, C.POINTER(C.c_uint32)), shape=(4, 8))
+    r, g, b = (tex >> 16) & 255, (tex >> 8) & 255, tex & 255
+    assert abs(int(r[0, 0]) - 200) <= 2 and abs(int(g[0, 0]) - 100) <= 2 and abs(int(b[0, 0]) - 50) <= 2
