@@ -219,3 +219,43 @@ def test_size_limits_are_rejected_before_any_work(gpu, cornell):
     cam, sun = scenes.cornell_camera(div=120)
     fr = gpu.Frame(sc, cam, host.default_params(sun_pos=sun, global_illumination=0, num_samples=1 << 30))
     assert fr.num_pixels == 16 * 9
+
+
+def test_headline_frame_at_full_size(gpu):
+    """The bench workload at its real size (262 k triangles, 1920x1080, 128 samples, GI), checked through
+    properties that do not need the whole oracle image: the pass size and the tile shards do not change
+    a single pixel, every pixel is a colour, and one image row of ids and direct light equals the oracle's
+    brute-force search bit for bit."""
+    big = host.HostScene.atrium(abi.SCENE_CRYTEK, 262000, 128, 1)
+    cam, sun = scenes.crytek_camera(div=1)
+    sc = gpu.Scene(big.desc)
+    npx = 1920 * 1080
+    full = host.default_params(sun_pos=sun, global_illumination=1, num_samples=128)
+    ref, ids, st = sc.render(cam, full)
+    assert st.closest_rays + st.shadow_rays > 1.2e9 and st.samples_done == 128
+    assert np.isfinite(ref).all() and ref.min() >= 0 and ref.max() <= 255
+    assert (ids >= 0).mean() > 0.9
+    # smaller passes: same image
+    img, _, _ = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=128, chunk_samples=24))
+    assert np.array_equal(img, ref)
+    # eight tile shards, summed as the multi-GPU run sums them
+    total = np.zeros(npx * 3, dtype=np.float32)
+    first = None
+    for r in range(8):
+        fr = gpu.Frame(sc, cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=128, shard_rank=r, shard_count=8))
+        acc = gpu.DeviceBuffer(npx * 12)
+        fr.accumulate(acc.ptr)
+        total += acc.to_host()
+        if first is None:
+            first = fr
+    acc, out = gpu.DeviceBuffer(npx * 12), gpu.DeviceBuffer(npx * 12)
+    acc.from_host(total)
+    first.finalize(acc.ptr, out.ptr)
+    assert np.array_equal(out.to_host().reshape(1080, 1920, 3), ref)
+    # one row against the oracle's brute-force search (direct light: no random numbers involved)
+    osc = ob.OracleScene(big.desc)
+    direct = host.default_params(sun_pos=sun, global_illumination=0)
+    dimg, dids, _ = sc.render(cam, direct)
+    oimg, _, otri, _ = osc.render(cam, direct, accel=ob.ACCEL_BRUTE, row_step=1080, row_phase=540)
+    assert np.array_equal(dids[540], otri[540]) and np.array_equal(ids[540], otri[540])
+    assert np.array_equal(dimg[540].view(np.uint32), oimg[540].view(np.uint32))
