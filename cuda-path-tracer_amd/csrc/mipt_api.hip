@@ -470,6 +470,7 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
         FRTRY(hipMalloc(&f->shadowQ.o, 16 * sc)); FRTRY(hipMalloc(&f->shadowQ.d, 16 * sc));
         FRTRY(hipMalloc(&f->hit, 16 * sc));
         FRTRY(hipMalloc(&f->pathState, 16 * 3 * sc));
+        FRTRY(hipMemset(f->pathState, 0, 16 * 3 * sc));      // once: afterwards every pass overwrites what it reads (see k_shade_bounce)
     }
     int32_t passes = (ns + chunk - 1) / chunk;
     f->numCounters = CTR_FIXED + CTR_PER_PASS * passes;
@@ -554,7 +555,6 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                 int64_t slots = (int64_t)nAct * Sn;
                 int32_t* C = f->counters + CTR_FIXED + CTR_PER_PASS * pass;
                 launch_set_i32(C + 0, (int32_t)slots, st);
-                HIPTRY(hipMemsetAsync(f->pathState, 0, 16 * 3 * (size_t)slots, st));
                 launch_gen_first_bounce(R, f->pixState, f->actPix, nAct, n0, Sn, f->q[0], st);
                 for (int level = 1; level <= 3; level++) {
                     int32_t* Lc = C + 4 * (level - 1);       // count, closest head, shadow count, shadow head

@@ -594,7 +594,8 @@ void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const i
 
 // ---------------------------------------------------------------------------------------
 // Bounce shading (Radiance at depth `level`, 1..3).  pathState[(level-1)*slots + slot] =
-// (direct term, albedo.xyz); it stays zero for a path that ended before this level.
+// (direct term, albedo.xyz), zero where the ray of this level missed; levels beyond the end of a path keep
+// whatever an earlier pass left there (finite numbers), which k_resolve multiplies by that zero.
 __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, RayQueue q, const float4* __restrict__ hit,
                                                      const int32_t* __restrict__ d_count, int32_t level,
                                                      const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
@@ -634,6 +635,10 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
             int tri = __float_as_int(h.w);
             bool isHit = inRange && tri >= 0;
+            // a ray that left the scene ends its path: the state of this level is zero.  Every slot that
+            // reaches a level is written here, hit or miss, so the buffer needs no clearing between passes
+            // (levels a path did not reach are multiplied by the zero albedo of the level where it ended)
+            if (inRange && !isHit) pathState[(size_t)(level - 1) * slotsPerLevel + __float_as_int(h.x)] = make_float4(0, 0, 0, 0);
             unsigned long long mask = __ballot(isHit);
             if (mask == 0) continue;
             int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
