@@ -72,9 +72,9 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 //
 // One wave per workgroup, one ray per lane, per-lane stack in LDS (entry k of lane l at
 // stack[k * 64 + l]: every lane of a half-wave hits its own bank; entries beyond the LDS part,
-// which only very deep trees need, live in a per-wave slice of global memory).  Waves are persistent: a wave
-// reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands them to its lanes
-// as soon as they fall idle.
+// which only very deep trees need, live in a per-wave slice of global memory).  Waves are
+// persistent: a wave reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands
+// them to its lanes as soon as they fall idle.
 //
 // Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  One round of the
 // loop hands rays to idle lanes, then runs a phase and writes the results of finished rays.  The
@@ -82,9 +82,10 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // have left for a leaf or finished; the triangle phase is a short run of triangle steps for the
 // lanes that wait at a triangle, entered when `triVote` of them do or no lane is at an inner node
 // and repeated while more than `triStay` eighths of them are still at a leaf.  Lanes of the other
-// kind sit a phase out.  A round runs the node phase and then the triangle phase.  A node step fetches one 64-byte node (one cache line per lane),
-// tests its four child boxes, sorts the children that were hit by entry distance, continues with
-// the nearest and pushes the others.  The thresholds were chosen by measurement (profiles/).
+// kind sit a phase out.  A round runs the node phase and then the triangle phase.  A node step
+// fetches one 64-byte node (one cache line per lane), tests its four child boxes, sorts the
+// children that were hit by entry distance, continues with the nearest and pushes the others.
+// The thresholds were chosen by measurement (profiles/).
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
@@ -140,9 +141,6 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     const int ldsCap = S.stackLds;
     uint32_t* spill = S.stackSpill ? S.stackSpill + (size_t)blockIdx.x * (size_t)(S.stackDepth - S.stackLds) * WAVE + lane : nullptr;
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
-#ifdef MIPT_ABL_VALU
-    float t0dummy = 1.0f;
-#endif
 #ifdef MIPT_TRACE_PROFILE
     uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0;
 #endif
