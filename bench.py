@@ -129,7 +129,10 @@ def main():
                        traversal_cost=float(os.environ.get("MIPT_BENCH_TCOST", "0")))
     info = dev.info()
 
-    shard = sharding.shard_fields(rank, world, samples, args.shard)
+    # tile shards: every rank traces, accumulates and finalizes its own tiles and the final images are added
+    # (disjoint pixels: exact); sample shards: the unclamped sums are added and rank 0 finalizes
+    own_tiles = world > 1 and args.shard == "tiles"
+    shard = sharding.shard_fields(rank, world, samples, args.shard, own_pixels_only=own_tiles)
     params = host.default_params(sun_pos=sun, global_illumination=gi, num_samples=samples, use_textures=1, use_normals=0,
                                  chunk_samples=args.chunk, **shard)
     frame = device.Frame(dev, cam, params)
@@ -137,17 +140,24 @@ def main():
     accum = torch.zeros(npx * 3, dtype=torch.float32, device="cuda")
     out = torch.zeros(npx * 3, dtype=torch.float32, device="cuda")
 
-    def step():
-        st = frame.accumulate(accum.data_ptr())
+    def reduce(t):
         if world > 1 and coll == "cpu":
-            host_sum = accum.cpu()
+            host_sum = t.cpu()
             sharding.reduce_to_rank0(host_sum, dist, world)
             if rank == 0:
-                accum.copy_(host_sum)
+                t.copy_(host_sum)
         else:
-            sharding.reduce_to_rank0(accum, dist, world)
-        if rank == 0:
+            sharding.reduce_to_rank0(t, dist, world)
+
+    def step():
+        st = frame.accumulate(accum.data_ptr())
+        if own_tiles:
             frame.finalize(accum.data_ptr(), out.data_ptr())
+            reduce(out)
+        else:
+            reduce(accum)
+            if rank == 0:
+                frame.finalize(accum.data_ptr(), out.data_ptr())
         return st
 
     def fence():

@@ -410,6 +410,7 @@ static int fill_render(mipt_frame* f, const mipt_camera* cam, const mipt_params*
     R.numSamples = ns;
     R.shardCount = p->shard_count > 1 ? p->shard_count : 1;
     R.shardRank = p->shard_rank;
+    R.ownPixelsOnly = (p->own_pixels_only != 0 && R.shardCount > 1) ? 1 : 0;
     if (R.shardRank < 0 || R.shardRank >= R.shardCount) return fail(MIPT_E_INVALID, "shard_rank %d outside 0..%d", p->shard_rank, R.shardCount - 1);
     R.tileSize = p->tile_size > 0 ? p->tile_size : 32;
     R.tilesX = (W + R.tileSize - 1) / R.tileSize;

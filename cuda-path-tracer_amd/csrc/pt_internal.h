@@ -71,6 +71,7 @@ struct DevRender {
     uint32_t seed;
     int32_t  numSamples;
     int32_t  shardRank, shardCount, tileSize, tilesX;
+    int32_t  ownPixelsOnly;   // primary rays of other shards' tiles are replaced by rays that miss the scene
 };
 
 // ---- statistics slots (uint64 each) ---------------------------------------------------

@@ -22,10 +22,19 @@
 // ---------------------------------------------------------------------------------------
 // k_raygen: CPUPathTracer.cpp:489-497 (the CPU flavour transforms (vx,vy,1) first and
 // normalises once; XMVector3TransformCoord/Normal evaluate ((z*r2 [+ r3]) + y*r1) + x*r0)
+__device__ __forceinline__ bool pixel_owned(const DevRender& R, int p);
+
 __global__ void __launch_bounds__(256) k_raygen(DevRender R, RayQueue q)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= R.W * R.H) return;
+    if (R.ownPixelsOnly && !pixel_owned(R, p)) {
+        // a pixel of another shard: a ray from far outside that points away misses the root box at once,
+        // the pixel is then shaded as a miss (black, id -1) and starts no paths
+        q.o[p] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(p));
+        q.d[p] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
     int j = p % R.W, h = p / R.W;
     const float* m = R.toLocal;
     float vx = (+2.0f * (float)R.div * j / (float)R.clientW - 1.0f) / R.p0;

@@ -43,7 +43,7 @@ class Params(C.Structure):
                 ("epsilon", C.c_float), ("normalize_normal_map", C.c_int32), ("seed", C.c_uint32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("tile_size", C.c_int32),
                 ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("chunk_samples", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("own_pixels_only", C.c_int32)]
 
 
 class BuildOptions(C.Structure):

@@ -7,12 +7,16 @@ shares are added on rank 0, which alone applies the final division, clamp and *2
 (PathTracer.cu:453-462, 550-552).  The clamp is not linear, so it must come after the sum."""
 
 
-def shard_fields(rank, world, num_samples, mode="tiles", tile_size=32):
-    """mipt_params fields for this rank."""
+def shard_fields(rank, world, num_samples, mode="tiles", tile_size=32, own_pixels_only=False):
+    """mipt_params fields for this rank.  own_pixels_only (tile mode): every rank traces and finalizes
+    its own tiles only and the FINAL images are added, instead of the unclamped sums."""
     if world <= 1:
         return dict(shard_rank=0, shard_count=1, tile_size=tile_size, sample_begin=0, sample_end=0)
     if mode == "tiles":
-        return dict(shard_rank=rank, shard_count=world, tile_size=tile_size, sample_begin=0, sample_end=0)
+        f = dict(shard_rank=rank, shard_count=world, tile_size=tile_size, sample_begin=0, sample_end=0)
+        if own_pixels_only:
+            f["own_pixels_only"] = 1
+        return f
     if mode == "samples":
         per = (num_samples + world - 1) // world
         begin = min(num_samples, rank * per)

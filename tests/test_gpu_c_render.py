@@ -259,3 +259,26 @@ def test_headline_frame_at_full_size(gpu):
     oimg, _, otri, _ = osc.render(cam, direct, accel=ob.ACCEL_BRUTE, row_step=1080, row_phase=540)
     assert np.array_equal(dids[540], otri[540]) and np.array_equal(ids[540], otri[540])
     assert np.array_equal(dimg[540].view(np.uint32), oimg[540].view(np.uint32))
+
+
+def test_tile_shards_that_finalize_their_own_pixels(gpu, cornell):
+    """own_pixels_only: every shard traces depth 0 for its tiles only and finalizes them; the final
+    images (black outside the shard) add up to the frame, bit for bit."""
+    cam, sun = scenes.cornell_camera(div=8)
+    sc = gpu.Scene(cornell.desc)
+    N, npx = 12, 240 * 135
+    ref, ref_ids, st_full = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=N))
+    total = np.zeros((135, 240, 3), dtype=np.float32)
+    ids = np.full((135, 240), -1, dtype=np.int32)
+    rays = 0
+    for r in range(4):
+        prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=N, shard_rank=r, shard_count=4, tile_size=16, own_pixels_only=1)
+        img, sid, st = sc.render(cam, prm)
+        assert ((img != 0).any(axis=2) <= (sid >= 0)).all()          # colour only where this shard traced
+        assert not ((total != 0).any(axis=2) & (img != 0).any(axis=2)).any()
+        total += img
+        ids = np.maximum(ids, sid)
+        rays += st.closest_rays + st.shadow_rays
+    assert np.array_equal(total, ref) and np.array_equal(ids, ref_ids)
+    # no duplicated work beyond the rays that leave the scene at once
+    assert rays <= st_full.closest_rays + st_full.shadow_rays + 4 * npx
