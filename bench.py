@@ -179,6 +179,7 @@ def main():
         float(sum(s.closest_ms for s in stats)), float(sum(s.closest_launches for s in stats)),
         float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
         float(sum(s.shadow_ms for s in stats)), float(sum(s.closest_rays for s in stats)),
+        float(sum(s.shade_ms for s in stats)),
     ], dtype=torch.float64, device=coll)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if world > 1:
@@ -226,7 +227,8 @@ def main():
                 "closest_rays_per_s": tot[8].item() / closest_s if closest_s > 0 else 0.0,
                 "algorithmic_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
                 "hbm_frac": (bytes_ / closest_s / 1e9) / HBM_PEAK_GBS if closest_s > 0 else 0.0,
-                "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed)},
+                "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed),
+                                      "shading": tot[9].item() / (1e3 * elapsed)},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

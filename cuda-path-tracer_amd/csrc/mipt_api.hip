@@ -215,6 +215,7 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
         off = 0; dw = dh = 0; dfmt = MIPT_TEXFMT_NONE;
         if (!data || fmt == MIPT_TEX_NONE || w <= 0 || h <= 0) return MIPT_OK;
         if (fmt != MIPT_TEX_BGRA8 && fmt != MIPT_TEX_F32X3) return MIPT_E_INVALID;
+        if (w >= (1 << 30)) return MIPT_E_INVALID;       // the shading records keep the format in the two top bits of the width
         size_t cnt = (size_t)w * (size_t)h;
         slots.push_back({ &off, &dw, &dh, &dfmt, (int)jobs.size() });
         jobs.emplace_back(new TexJob(data, fmt, cnt, pool8Count));
@@ -228,7 +229,7 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
         memset(&d, 0, sizeof(d));
         if (addTex(m.tex_data, m.tex_width, m.tex_height, m.tex_format, d.texOffset, d.texW, d.texH, d.texFmt) ||
             addTex(m.nml_data, m.nml_width, m.nml_height, m.nml_format, d.nmlOffset, d.nmlW, d.nmlH, d.nmlFmt))
-            return fail(MIPT_E_INVALID, "material %d has an unknown texel format", i);
+            return fail(MIPT_E_INVALID, "material %d has an unknown texel format or a texture wider than 2^30", i);
         d.diffuse[0] = m.diffuse[0]; d.diffuse[1] = m.diffuse[1]; d.diffuse[2] = m.diffuse[2];
     }
     std::unique_ptr<uint32_t[]> pool8(pool8Count ? new uint32_t[pool8Count] : nullptr);
@@ -276,7 +277,7 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     if (n > 0) {
         // per-triangle shading records; the corner arrays are only needed to make them and the BVH
         SCTRY(hipMalloc(&s->shade, sizeof(float4) * MIPT_SHADE_F4 * (size_t)n));
-        launch_make_shading(s->attr, s->triMat, n, s->shade, s->stream);
+        launch_make_shading(s->attr, s->triMat, s->mats, n, s->shade, s->stream);
         SCTRY(hipStreamSynchronize(s->stream));
         SCTRY(hipGetLastError());
         (void)hipFree(s->attr); s->attr = nullptr;
@@ -558,16 +559,18 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                 launch_set_i32(C + 0, (int32_t)slots, st);
                 launch_gen_first_bounce(R, f->pixState, f->actPix, nAct, n0, Sn, f->q[0], st);
                 for (int level = 1; level <= 3; level++) {
-                    int32_t* Lc = C + 4 * (level - 1);       // count, closest head, shadow count, shadow head
-                    int32_t* nextCount = (level < 3) ? C + 4 * level : nullptr;
+                    // per level: closest head, hit count (= shadow rays = rays of the next level), shadow head;
+                    // the rays of level 1 are counted in C[0]
+                    int32_t* Lc = C + 1 + 3 * (level - 1);
+                    const int32_t* inCount = (level == 1) ? C : Lc - 2;
                     RayQueue cur = f->q[(level - 1) & 1], nxt = f->q[level & 1];
                     spanBegin(0);
-                    launch_closest(S, cur, Lc + 0, (int32_t)slots, Lc + 1, f->hit, R.eps, f->stats, g_numCUs, st, true);
+                    launch_closest(S, cur, inCount, (int32_t)slots, Lc + 0, f->hit, R.eps, f->stats, g_numCUs, st, true);
                     spanEnd();
-                    launch_shade_bounce(S, R, cur, f->hit, Lc + 0, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
-                                        f->shadowQ, Lc + 2, nxt, nextCount, st);
+                    launch_shade_bounce(S, R, cur, f->hit, inCount, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
+                                        f->shadowQ, nxt, Lc + 1, st);
                     spanBegin(1);
-                    launch_shadow(S, f->shadowQ, Lc + 2, (int32_t)slots, Lc + 3, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
+                    launch_shadow(S, f->shadowQ, Lc + 1, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
                     spanEnd();
                 }
                 launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);

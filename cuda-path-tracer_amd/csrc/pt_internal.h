@@ -25,7 +25,7 @@
 #endif
 #define MIPT_NODE_WIDTH 4
 #define MIPT_STACK_LDS_MAX 22   // stack entries per lane kept in LDS (5.5 KiB per wave: 28 waves per compute unit)
-#define MIPT_SHADE_F4 5
+#define MIPT_SHADE_F4 8
 #define MIPT_LEAF_BIT 0x80000000u
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
@@ -110,7 +110,7 @@ struct RayQueue {
 
 void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s);
 // closest-hit over q[0 .. *d_count): hit[i] = (t, ua, va, bits triangle id or -1)
-void launch_make_shading(const float4* attr, const int32_t* triMat, int64_t n, float4* shade, hipStream_t s);
+void launch_make_shading(const float4* attr, const int32_t* triMat, const DevMaterial* mats, int64_t n, float4* shade, hipStream_t s);
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit = false);
 // any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
@@ -131,7 +131,7 @@ void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const i
 void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
                          const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
                          int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                         int32_t* d_shadowCount, RayQueue nextQ, int32_t* d_nextCount, hipStream_t s);
+                         RayQueue nextQ, int32_t* d_outCount, hipStream_t s);
 // backward resolve of one pass and accumulation into the per-active-pixel sums
 void launch_resolve(const DevRender& R, const float4* pathState, int64_t slotsPerLevel, const int32_t* actPix,
                     int32_t nAct, int32_t n0, int32_t S, float4* pixAccum, hipStream_t s);

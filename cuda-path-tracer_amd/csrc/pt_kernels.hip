@@ -402,14 +402,18 @@ void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Shading record of a triangle, MIPT_SHADE_F4 float4 in a row so that a hit gathers one short run
-// of memory: the three positions, the material, the flat normal of CMesh::Intersect
-// (CPUPathTracer.cpp:236-243: normalised mean of the corner normals, the same for every hit of
-// the triangle) and the corner texture coordinates.
+// Shading record of a triangle: MIPT_SHADE_F4 float4 = one aligned 128-byte line, so that a hit
+// gathers a single line and needs no second, dependent fetch of its material: the three positions,
+// the flat normal of CMesh::Intersect (CPUPathTracer.cpp:236-243: normalised mean of the corner
+// normals, the same for every hit of the triangle), the corner texture coordinates and a copy of
+// the material's texture descriptors.
 //   [0] = (p0, bits material)  [1] = (p1, N.x)  [2] = (p2, N.y)  [3] = (t0.x, t0.y, t1.x, t1.y)  [4] = (t2.x, t2.y, N.z, 0)
+//   [5] = bits (first texel low, high, width | format << 30, height) of the colour texture
+//   [6] = (diffuse colour, 0)
+//   [7] = the same four words as [5] for the normal map
 // attr holds the corners as the caller gave them: 2 float4 each = (pos3, normal3, tex2).
 __global__ void __launch_bounds__(256) k_make_shading(const float4* __restrict__ attr, const int32_t* __restrict__ triMat,
-                                                     int64_t n, float4* shade)
+                                                     const DevMaterial* __restrict__ mats, int64_t n, float4* shade)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -421,17 +425,25 @@ __global__ void __launch_bounds__(256) k_make_shading(const float4* __restrict__
     nn.y = (a1.x + a3.x + a5.x) / 3;
     nn.z = (a1.y + a3.y + a5.y) / 3;
     F3 N = f3normalize(nn);
+    int mi = triMat[i];
+    DevMaterial M = {};
+    if (mi >= 0) M = mats[mi];
     float4* o = shade + (size_t)i * MIPT_SHADE_F4;
-    o[0] = make_float4(a0.x, a0.y, a0.z, __int_as_float(triMat[i]));
+    o[0] = make_float4(a0.x, a0.y, a0.z, __int_as_float(mi));
     o[1] = make_float4(a2.x, a2.y, a2.z, N.x);
     o[2] = make_float4(a4.x, a4.y, a4.z, N.y);
     o[3] = make_float4(a1.z, a1.w, a3.z, a3.w);
     o[4] = make_float4(a5.z, a5.w, N.z, 0.0f);
+    o[5] = make_float4(__uint_as_float((uint32_t)M.texOffset), __uint_as_float((uint32_t)(M.texOffset >> 32)),
+                       __uint_as_float((uint32_t)M.texW | ((uint32_t)M.texFmt << 30)), __int_as_float(M.texH));
+    o[6] = make_float4(M.diffuse[0], M.diffuse[1], M.diffuse[2], 0.0f);
+    o[7] = make_float4(__uint_as_float((uint32_t)M.nmlOffset), __uint_as_float((uint32_t)(M.nmlOffset >> 32)),
+                       __uint_as_float((uint32_t)M.nmlW | ((uint32_t)M.nmlFmt << 30)), __int_as_float(M.nmlH));
 }
-void launch_make_shading(const float4* attr, const int32_t* triMat, int64_t n, float4* shade, hipStream_t s)
+void launch_make_shading(const float4* attr, const int32_t* triMat, const DevMaterial* mats, int64_t n, float4* shade, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_make_shading, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, attr, triMat, n, shade);
+    hipLaunchKernelGGL(k_make_shading, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, attr, triMat, mats, n, shade);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -470,17 +482,19 @@ __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender
     sf.hp.z = w * r0.z + ua * r1.z + va * r2.z;
     sf.N = f3(r1.w, r2.w, r4.z);                        // normalised mean of the corner normals, :236-243, made once per triangle
 
-    int mi = __float_as_int(r0.w);
     F3 nmlMap = f3(0, 1, 0);
     long texW = 0, texH = 0, nmlW = 0, nmlH = 0;
     int texFmt = MIPT_TEXFMT_NONE, nmlFmt = MIPT_TEXFMT_NONE;
     uint64_t texOff = 0, nmlOff = 0;
-    F3 diffuse = f3(0, 0, 0);
-    if (mi >= 0) {
-        const DevMaterial& M = S.mats[mi];
-        texW = M.texW; texH = M.texH; texFmt = M.texFmt; texOff = M.texOffset;
-        nmlW = M.nmlW; nmlH = M.nmlH; nmlFmt = M.nmlFmt; nmlOff = M.nmlOffset;
-        diffuse = f3(M.diffuse[0], M.diffuse[1], M.diffuse[2]);
+    if (R.useTextures) {
+        float4 t = a[5];
+        texOff = (uint64_t)__float_as_uint(t.x) | ((uint64_t)__float_as_uint(t.y) << 32);
+        texW = (long)(__float_as_uint(t.z) & 0x3fffffffu); texFmt = (int)(__float_as_uint(t.z) >> 30); texH = __float_as_int(t.w);
+    }
+    if (R.useNormals) {
+        float4 t = a[7];
+        nmlOff = (uint64_t)__float_as_uint(t.x) | ((uint64_t)__float_as_uint(t.y) << 32);
+        nmlW = (long)(__float_as_uint(t.z) & 0x3fffffffu); nmlFmt = (int)(__float_as_uint(t.z) >> 30); nmlH = __float_as_int(t.w);
     }
     u = wrap01(u); v = wrap01(v);
     if (nmlFmt != MIPT_TEXFMT_NONE && (R.useNormals)) {      // the map only matters when it is applied
@@ -503,7 +517,8 @@ __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender
         uint32_t dw = fetch_texel_bgr(S, texFmt, texOff, h * texW + j);
         sf.albedo = f3((float)(dw & 255u) / 255.0f, (float)((dw >> 8) & 255u) / 255.0f, (float)((dw >> 16) & 255u) / 255.0f);
     } else {
-        sf.albedo = diffuse;                                  // :338
+        float4 dc = a[6];
+        sf.albedo = f3(dc.x, dc.y, dc.z);                     // :338
     }
     coordinate_system(sf.N, sf.Nt, sf.Nb);                    // :389
     if (R.useNormals) {                                       // :390-400
@@ -614,7 +629,7 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
                                                      const int32_t* __restrict__ d_count, int32_t level,
                                                      const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
                                                      float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                                                     int32_t* shadowCount, RayQueue nextQ, int32_t* nextCount)
+                                                     RayQueue nextQ, int32_t* outCount)
 {
     const int n = *d_count;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -623,9 +638,9 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
     const int64_t numWaves = (int64_t)gridDim.x * wavesPerBlock;
     const bool spawnLevel = level < 3;          // a sample drawn at depth 3 is not traced (PathTracer.cu:380)
     // a wave owns SHADE_ITEMS * 64 consecutive queue entries at a time; it first counts its hits
-    // (one ballot per 64 entries) and reserves their places in the output queues with ONE atomic
-    // per queue, then shades and writes.  Both output queues receive the same entries in the same
-    // order, so one reservation index serves both.
+    // (one ballot per 64 entries) and reserves their places in the output queues with one atomic,
+    // then shades and writes.  Both output queues receive the same entries at the same places, so
+    // one counter serves both.
     for (int64_t first = wave * (SHADE_ITEMS * WAVE); first < n; first += numWaves * (SHADE_ITEMS * WAVE)) {
         int total = 0;
         #pragma unroll
@@ -635,13 +650,10 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             total += __popcll(__ballot(h));
         }
         if (total == 0) continue;
-        int sbase = 0, nbase = 0;
-        if (lane == 0) {
-            sbase = atomicAdd(shadowCount, total);
-            if (spawnLevel) nbase = atomicAdd(nextCount, total);
-        }
+        int sbase = 0;
+        if (lane == 0) sbase = atomicAdd(outCount, total);
         sbase = __builtin_amdgcn_readfirstlane(sbase);
-        nbase = __builtin_amdgcn_readfirstlane(nbase);
+        const int nbase = sbase;
         int running = 0;
         for (int k = 0; k < SHADE_ITEMS; k++) {
             int64_t i = first + k * WAVE + lane;
@@ -683,14 +695,14 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
 void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
                          const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
                          int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                         int32_t* d_shadowCount, RayQueue nextQ, int32_t* d_nextCount, hipStream_t s)
+                         RayQueue nextQ, int32_t* d_outCount, hipStream_t s)
 {
     if (maxCount <= 0) return;
     const int perBlock = (256 / WAVE) * SHADE_ITEMS * WAVE;
     long long blocks = ((long long)maxCount + perBlock - 1) / perBlock;
     if (blocks > 256 * 32) blocks = 256 * 32;      // waves stride over the queue beyond this
     hipLaunchKernelGGL(k_shade_bounce, dim3((unsigned)blocks), dim3(256), 0, s, S, R, q, hit, d_count, level, actPix, nAct, n0,
-                       pathState, slotsPerLevel, shadowQ, d_shadowCount, nextQ, d_nextCount);
+                       pathState, slotsPerLevel, shadowQ, nextQ, d_outCount);
 }
 
 // ---------------------------------------------------------------------------------------

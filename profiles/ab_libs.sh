@@ -11,6 +11,6 @@ for L in base "$@"; do
   name=$(basename "$L" .so)
   timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1 || { echo "$name failed"; break; }
   python3 -c "
-import json,sys; d=json.loads(open('$OUT/$name.log').read().strip().splitlines()[-1]); print('$name', round(d['ms_per_step'],1), 'closest', round(d['roofline']['avg_launch_ms'],2))"
+import json,sys; d=json.loads(open('$OUT/$name.log').read().strip().splitlines()[-1]); k=d['roofline']['kernel_time_share']; print('$name', round(d['ms_per_step'],1), 'closest', round(d['roofline']['avg_launch_ms'],2), {n: round(v*d['ms_per_step'],1) for n,v in k.items()})"
 done
 rm -f "$OUT/base.so"
