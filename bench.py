@@ -174,12 +174,12 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([
-        float(sum(s.closest_rays + s.shadow_rays for s in stats)),
+        float(sum(s.closest_rays + s.shadow_rays + s.shadow_rays_culled for s in stats)),
         float(sum(s.closest_triangle_tests for s in stats)), float(sum(s.closest_node_visits for s in stats)),
         float(sum(s.closest_ms for s in stats)), float(sum(s.closest_launches for s in stats)),
         float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
         float(sum(s.shadow_ms for s in stats)), float(sum(s.closest_rays for s in stats)),
-        float(sum(s.shade_ms for s in stats)),
+        float(sum(s.shade_ms for s in stats)), float(sum(s.shadow_rays_culled for s in stats)),
     ], dtype=torch.float64, device=coll)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if world > 1:
@@ -187,9 +187,9 @@ def main():
         # rays and counters add over ranks; kernel time is per-rank wall time of rank 0's kernels
         sums = tot.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        total_rays = sums[0].item()
+        total_rays, culled_rays = sums[0].item(), sums[10].item()
     else:
-        total_rays = tot[0].item()
+        total_rays, culled_rays = tot[0].item(), tot[10].item()
     elapsed = tmax.item()
 
     if rank == 0:
@@ -212,6 +212,10 @@ def main():
                 "materials": int(info.num_materials), "image": f"{cam.image_size[0]}x{cam.image_size[1]}",
                 "samples": samples, "global_illumination": bool(gi), "textures": True, "normal_maps": False,
                 "parallelism": f"{args.shard}x{world}", "rays_per_frame": total_rays / args.steps,
+                # rays_per_frame counts the rays the reference algorithm casts for this frame (one closest-hit and one
+                # shadow query per path vertex); shadow queries whose answer cannot change the image are answered
+                # without a traversal and are listed here
+                "shadow_rays_not_traversed_per_frame": culled_rays / args.steps,
                 "render_time_s": elapsed / args.steps, "bvh_build_ms": info.build_ms, "bvh_depth": int(info.max_depth),
                 "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "image_sha1": image_sha1, "samples_per_pass": int(s0.chunk_samples),
             },

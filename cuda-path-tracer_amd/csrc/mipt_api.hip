@@ -59,7 +59,7 @@ struct mipt_frame {
     RayQueue primQ = {}; float4* primHit = nullptr; float4* pixState = nullptr; int32_t* triId = nullptr;
     int32_t* actPix = nullptr; float4* pixAccum = nullptr; RayQueue primShadowQ = {};
     // per path slot
-    RayQueue q[2] = {}; RayQueue shadowQ = {}; float4* hit = nullptr; float4* pathState = nullptr;
+    RayQueue q[2] = {}; RayQueue shadowQ = {}; int32_t* shadowBlocks = nullptr; float4* hit = nullptr; float4* pathState = nullptr;
     // counters
     int32_t* counters = nullptr; int32_t numCounters = 0;
     unsigned long long* stats = nullptr;
@@ -425,7 +425,7 @@ void mipt_frame_destroy(mipt_frame* f)
 {
     if (!f) return;
     void* ptrs[] = { f->primQ.o, f->primQ.d, f->primHit, f->pixState, f->triId, f->actPix, f->pixAccum, f->primShadowQ.o, f->primShadowQ.d,
-                     f->q[0].o, f->q[0].d, f->q[1].o, f->q[1].d, f->shadowQ.o, f->shadowQ.d, f->hit, f->pathState, f->counters, f->stats };
+                     f->q[0].o, f->q[0].d, f->q[1].o, f->q[1].d, f->shadowQ.o, f->shadowQ.d, f->shadowBlocks, f->hit, f->pathState, f->counters, f->stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : f->events) (void)hipEventDestroy(e);
     delete f;
@@ -470,6 +470,7 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
         size_t sc = (size_t)f->slotCap;
         for (int k = 0; k < 2; k++) { FRTRY(hipMalloc(&f->q[k].o, 16 * sc)); FRTRY(hipMalloc(&f->q[k].d, 16 * sc)); }
         FRTRY(hipMalloc(&f->shadowQ.o, 16 * sc)); FRTRY(hipMalloc(&f->shadowQ.d, 16 * sc));
+        FRTRY(hipMalloc(&f->shadowBlocks, 4 * ((sc >> MIPT_QBLOCK_SHIFT) + 1)));
         FRTRY(hipMalloc(&f->hit, 16 * sc));
         FRTRY(hipMalloc(&f->pathState, 16 * 3 * sc));
         FRTRY(hipMemset(f->pathState, 0, 16 * 3 * sc));      // once: afterwards every pass overwrites what it reads (see k_shade_bounce)
@@ -527,9 +528,9 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     spanBegin(0);
     launch_closest(S, f->primQ, f->counters + 0, P, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st);
     spanEnd();
-    launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, st);
+    launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, f->stats, st);
     spanBegin(1);
-    launch_shadow(S, f->primShadowQ, f->counters + 2, P, f->counters + 3, f->pixState, f->pathState, f->slotCap, R.eps, f->stats, g_numCUs, st);
+    launch_shadow(S, f->primShadowQ, f->counters + 2, nullptr, P, f->counters + 3, f->pixState, f->pathState, f->slotCap, R.eps, f->stats, g_numCUs, st);
     spanEnd();
 
     int32_t nAct = 0;
@@ -559,7 +560,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                 launch_set_i32(C + 0, (int32_t)slots, st);
                 launch_gen_first_bounce(R, f->pixState, f->actPix, nAct, n0, Sn, f->q[0], st);
                 for (int level = 1; level <= 3; level++) {
-                    // per level: closest head, hit count (= shadow rays = rays of the next level), shadow head;
+                    // per level: closest head, hit count (= rays of the next level), shadow head;
                     // the rays of level 1 are counted in C[0]
                     int32_t* Lc = C + 1 + 3 * (level - 1);
                     const int32_t* inCount = (level == 1) ? C : Lc - 2;
@@ -568,9 +569,9 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     launch_closest(S, cur, inCount, (int32_t)slots, Lc + 0, f->hit, R.eps, f->stats, g_numCUs, st, true);
                     spanEnd();
                     launch_shade_bounce(S, R, cur, f->hit, inCount, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
-                                        f->shadowQ, nxt, Lc + 1, st);
+                                        f->shadowQ, f->shadowBlocks, nxt, Lc + 1, f->stats, st);
                     spanBegin(1);
-                    launch_shadow(S, f->shadowQ, Lc + 1, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
+                    launch_shadow(S, f->shadowQ, inCount, f->shadowBlocks, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
                     spanEnd();
                 }
                 launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);
@@ -597,7 +598,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         memset(stats, 0, sizeof(*stats));
         unsigned long long h[ST_COUNT];
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
-        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS];
+        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED];
 #ifdef MIPT_TRACE_PROFILE
         fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu\n",
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6]);

@@ -26,6 +26,8 @@
 #define MIPT_NODE_WIDTH 4
 #define MIPT_STACK_LDS_MAX 22   // stack entries per lane kept in LDS (5.5 KiB per wave: 28 waves per compute unit)
 #define MIPT_SHADE_F4 8
+// A queue in blocks: entries [b << MIPT_QBLOCK_SHIFT, (b << MIPT_QBLOCK_SHIFT) + blockCount[b]) of every block b are valid
+#define MIPT_QBLOCK_SHIFT 10
 #define MIPT_LEAF_BIT 0x80000000u
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
@@ -77,6 +79,7 @@ struct DevRender {
 // ---- statistics slots (uint64 each) ---------------------------------------------------
 enum {
     ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
+    ST_SHADOW_CULLED, // shadow rays that were not traced because the direct term they guard is zero
     ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel, 8 entries
     ST_COUNT = 16
 };
@@ -114,7 +117,7 @@ void launch_make_shading(const float4* attr, const int32_t* triMat, const DevMat
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit = false);
 // any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
-void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
                    unsigned long long* d_stats, int numCUs, hipStream_t s);
 // any-hit for caller-supplied rays: out[i] = 1 if occluded
@@ -123,7 +126,7 @@ void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, 
 // shading of the primary hits (level 0)
 void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* hit, float4* pixState,
                           int32_t* triIdImage, RayQueue shadowQ, int32_t* d_shadowCount, int32_t* actPix,
-                          int32_t* d_actCount, hipStream_t s);
+                          int32_t* d_actCount, unsigned long long* d_stats, hipStream_t s);
 // first-bounce rays of samples [n0, n0+S) of every active pixel
 void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const int32_t* actPix, int32_t nAct,
                              int32_t n0, int32_t S, RayQueue q, hipStream_t s);
@@ -131,7 +134,8 @@ void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const i
 void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
                          const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
                          int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                         RayQueue nextQ, int32_t* d_outCount, hipStream_t s);
+                         int32_t* d_shadowBlockCount, RayQueue nextQ, int32_t* d_nextCount,
+                         unsigned long long* d_stats, hipStream_t s);
 // backward resolve of one pass and accumulation into the per-active-pixel sums
 void launch_resolve(const DevRender& R, const float4* pathState, int64_t slotsPerLevel, const int32_t* actPix,
                     int32_t nAct, int32_t n0, int32_t S, float4* pixAccum, hipStream_t s);

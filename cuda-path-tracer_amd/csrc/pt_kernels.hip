@@ -83,7 +83,10 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
 // stack[k * 64 + l]: every lane of a half-wave hits its own bank; entries beyond the LDS part,
 // which only very deep trees need, live in a per-wave slice of global memory).  Waves are
 // persistent: a wave reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands
-// them to its lanes as soon as they fall idle.
+// them to its lanes as soon as they fall idle.  The queue is either dense (entries 0 .. count-1) or
+// in blocks of 1 << MIPT_QBLOCK_SHIFT entries of which the first blockCount[b] are valid (the
+// shadow rays of bounce shading, which writes them without any atomic); a reservation never
+// straddles a block.
 //
 // Every lane is at an inner node, at a triangle of a leaf, finished, or idle.  One round of the
 // loop hands rays to idle lanes, then runs a phase and writes the results of finished rays.  The
@@ -145,7 +148,7 @@ __device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32
 
 template <int MODE>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
-                                               int32_t* head, float4* __restrict__ hit, float4* pixState0,
+                                               const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
                                                float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagInHit)
 {
@@ -178,12 +181,16 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         // ---- hand rays to idle lanes
         unsigned long long idleMask = __ballot(cur == LANE_IDLE);
         if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
-            if (rangeNext >= rangeEnd) {
+            // a queue in blocks can hold reservations without a valid entry: a few more are tried at once
+            for (int tries = 0; tries < 4 && rangeNext >= rangeEnd && !queueDry; tries++) {
                 int b = 0;
                 if (lane == 0) b = atomicAdd(head, chunk);
                 b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= n) queueDry = true;
-                else { rangeNext = b; rangeEnd = (b + chunk < n) ? b + chunk : n; }
+                if (b >= n) { queueDry = true; break; }
+                int end = n;
+                if (blockCount) end = ((b >> MIPT_QBLOCK_SHIFT) << MIPT_QBLOCK_SHIFT) + blockCount[b >> MIPT_QBLOCK_SHIFT];
+                rangeNext = b; rangeEnd = (b + chunk < end) ? b + chunk : end;
+                if (!blockCount) break;
             }
             int avail = rangeEnd - rangeNext;
             if (avail > 0) {
@@ -382,22 +389,24 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit)
 {
     size_t smem = trace_smem(S);
-    hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head, hit,
+    hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
                        (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0);
 }
-void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
+void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
                    unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
-    hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
+    int chunk = trace_chunk();
+    if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK;   // must divide a block
+    hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
+                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
-    hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_head,
+    hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
                        (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
 }
 
@@ -539,6 +548,11 @@ __device__ __forceinline__ float direct_term(const DevRender& R, const Surface& 
     return R.sunIntensity * ((0.0f > dp) ? 0.0f : dp);
 }
 
+// The shadow ray only decides whether the direct term D is kept or replaced by +0
+// (CPUPathTracer.cpp:402-409).  Where D is +0 already (the surface faces away from the sun) the
+// answer changes nothing and the ray is not traced.
+__device__ __forceinline__ bool shadow_matters(float D) { return __float_as_uint(D) != 0u; }
+
 __device__ __forceinline__ bool pixel_owned(const DevRender& R, int p)
 {
     if (R.shardCount <= 1) return true;
@@ -552,7 +566,8 @@ __device__ __forceinline__ bool pixel_owned(const DevRender& R, int p)
 //   [2] = (N.xyz, Nt.x)                  [3] = (Nt.y, Nt.z, 0, 0)
 __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, const float4* __restrict__ hit,
                                                       float4* pixState, int32_t* triIdImage, RayQueue shadowQ,
-                                                      int32_t* shadowCount, int32_t* actPix, int32_t* actCount)
+                                                      int32_t* shadowCount, int32_t* actPix, int32_t* actCount,
+                                                      unsigned long long* stats)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     int n = R.W * R.H;
@@ -561,10 +576,12 @@ __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, 
     int tri = __float_as_int(h.w);
     bool isHit = inRange && tri >= 0;
     F3 so = f3(0, 0, 0), sd = f3(0, 0, 0);
+    bool wantShadow = false;
     if (inRange) triIdImage[p] = tri;
     if (isHit) {
         Surface sf = surface_at(S, R, tri, h.y, h.z);
         float D = direct_term(R, sf, so, sd);
+        wantShadow = shadow_matters(D);
         pixState[(size_t)p * 4 + 0] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
         pixState[(size_t)p * 4 + 1] = make_float4(sf.hp.x, sf.hp.y, sf.hp.z, 1.0f);
         pixState[(size_t)p * 4 + 2] = make_float4(sf.N.x, sf.N.y, sf.N.z, sf.Nt.x);
@@ -573,11 +590,13 @@ __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, 
         pixState[(size_t)p * 4 + 0] = make_float4(0, 0, 0, 0);
         pixState[(size_t)p * 4 + 1] = make_float4(0, 0, 0, 0);
     }
-    int si = wave_append(isHit, shadowCount);
-    if (isHit) {
+    int si = wave_append(wantShadow, shadowCount);
+    if (wantShadow) {
         shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(p));
         shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(0));
     }
+    unsigned long long culled = __ballot(isHit && !wantShadow);
+    if (culled && lane_id() == 0) atomicAdd(&stats[ST_SHADOW_CULLED], (unsigned long long)__popcll(culled));
     bool active = isHit && R.gi && pixel_owned(R, p);
     int ai = wave_append(active, actCount);
     if (active) actPix[ai] = p;
@@ -585,11 +604,11 @@ __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, 
 
 void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* hit, float4* pixState,
                           int32_t* triIdImage, RayQueue shadowQ, int32_t* d_shadowCount, int32_t* actPix,
-                          int32_t* d_actCount, hipStream_t s)
+                          int32_t* d_actCount, unsigned long long* d_stats, hipStream_t s)
 {
     int n = R.W * R.H;
     hipLaunchKernelGGL(k_shade_primary, dim3((n + 255) / 256), dim3(256), 0, s, S, R, hit, pixState, triIdImage, shadowQ,
-                       d_shadowCount, actPix, d_actCount);
+                       d_shadowCount, actPix, d_actCount, d_stats);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -629,7 +648,8 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
                                                      const int32_t* __restrict__ d_count, int32_t level,
                                                      const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
                                                      float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                                                     RayQueue nextQ, int32_t* outCount)
+                                                     int32_t* shadowBlockCount, RayQueue nextQ, int32_t* nextCount,
+                                                     unsigned long long* stats)
 {
     const int n = *d_count;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -637,10 +657,12 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
     const int64_t wave = (int64_t)blockIdx.x * wavesPerBlock + threadIdx.x / WAVE;
     const int64_t numWaves = (int64_t)gridDim.x * wavesPerBlock;
     const bool spawnLevel = level < 3;          // a sample drawn at depth 3 is not traced (PathTracer.cu:380)
-    // a wave owns SHADE_ITEMS * 64 consecutive queue entries at a time; it first counts its hits
-    // (one ballot per 64 entries) and reserves their places in the output queues with one atomic,
-    // then shades and writes.  Both output queues receive the same entries at the same places, so
-    // one counter serves both.
+    // a wave owns one block of SHADE_ITEMS * 64 consecutive queue entries at a time.  It first counts
+    // its hits (one ballot per 64 entries) and reserves their places in the queue of the next level
+    // with one atomic, then shades and writes.  Its shadow rays go to the same block of the shadow
+    // queue, packed from the start of the block, and their number to shadowBlockCount: no atomic,
+    // and every block of the input writes its count.
+    uint32_t culledCount = 0;
     for (int64_t first = wave * (SHADE_ITEMS * WAVE); first < n; first += numWaves * (SHADE_ITEMS * WAVE)) {
         int total = 0;
         #pragma unroll
@@ -649,12 +671,12 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             bool h = (i < n) && (__float_as_int(hit[i].w) >= 0);
             total += __popcll(__ballot(h));
         }
-        if (total == 0) continue;
-        int sbase = 0;
-        if (lane == 0) sbase = atomicAdd(outCount, total);
-        sbase = __builtin_amdgcn_readfirstlane(sbase);
-        const int nbase = sbase;
-        int running = 0;
+        int nbase = 0;
+        if (total != 0 && spawnLevel) {
+            if (lane == 0) nbase = atomicAdd(nextCount, total);
+            nbase = __builtin_amdgcn_readfirstlane(nbase);
+        }
+        int running = 0, shadowRun = 0;
         for (int k = 0; k < SHADE_ITEMS; k++) {
             int64_t i = first + k * WAVE + lane;
             bool inRange = i < n;
@@ -670,14 +692,15 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             int idx = running + prefix;
             running += __popcll(mask);
+            bool wantShadow = false;
+            int slot = 0;
+            F3 so = f3(0, 0, 0), sd = f3(0, 0, 0);
             if (isHit) {
-                int slot = __float_as_int(h.x);           // the traversal put the ray's slot id where the distance would be
+                slot = __float_as_int(h.x);               // the traversal put the ray's slot id where the distance would be
                 Surface sf = surface_at(S, R, tri, h.y, h.z);
-                F3 so, sd;
                 float D = direct_term(R, sf, so, sd);
+                wantShadow = shadow_matters(D);
                 pathState[(size_t)(level - 1) * slotsPerLevel + slot] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
-                shadowQ.o[sbase + idx] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
-                shadowQ.d[sbase + idx] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
                 if (spawnLevel) {
                     int a = slot % nAct, s = slot / nAct;
                     uint32_t p = (uint32_t)actPix[a], smp = (uint32_t)(n0 + s);
@@ -688,21 +711,33 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
                     nextQ.d[nbase + idx] = make_float4(nd.x, nd.y, nd.z, 0.0f);
                 }
             }
+            unsigned long long smask = __ballot(wantShadow);
+            if (wantShadow) {
+                int64_t si = first + shadowRun + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u));
+                shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
+                shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
+            }
+            shadowRun += __popcll(smask);
         }
+        if (lane == 0) shadowBlockCount[first >> MIPT_QBLOCK_SHIFT] = shadowRun;
+        culledCount += (uint32_t)(total - shadowRun);
     }
+    if (lane == 0 && culledCount) atomicAdd(&stats[ST_SHADOW_CULLED], (unsigned long long)culledCount);
 }
 
 void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,
                          const int32_t* d_count, int32_t maxCount, int32_t level, const int32_t* actPix,
                          int32_t nAct, int32_t n0, float4* pathState, int64_t slotsPerLevel, RayQueue shadowQ,
-                         RayQueue nextQ, int32_t* d_outCount, hipStream_t s)
+                         int32_t* d_shadowBlockCount, RayQueue nextQ, int32_t* d_nextCount,
+                         unsigned long long* d_stats, hipStream_t s)
 {
+    static_assert(SHADE_ITEMS * WAVE == (1 << MIPT_QBLOCK_SHIFT), "a wave shades one queue block at a time");
     if (maxCount <= 0) return;
     const int perBlock = (256 / WAVE) * SHADE_ITEMS * WAVE;
     long long blocks = ((long long)maxCount + perBlock - 1) / perBlock;
     if (blocks > 256 * 32) blocks = 256 * 32;      // waves stride over the queue beyond this
     hipLaunchKernelGGL(k_shade_bounce, dim3((unsigned)blocks), dim3(256), 0, s, S, R, q, hit, d_count, level, actPix, nAct, n0,
-                       pathState, slotsPerLevel, shadowQ, nextQ, d_outCount);
+                       pathState, slotsPerLevel, shadowQ, d_shadowBlockCount, nextQ, d_nextCount, d_stats);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ class SceneInfo(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("triangle_tests", C.c_uint64), ("closest_node_visits", C.c_uint64),
-                ("closest_triangle_tests", C.c_uint64), ("active_pixels", C.c_uint64), ("reserved0", C.c_uint64),
+                ("closest_triangle_tests", C.c_uint64), ("active_pixels", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("closest_launches", C.c_int32), ("shadow_launches", C.c_int32),
                 ("chunk_samples", C.c_int32), ("samples_done", C.c_int32)]

@@ -151,13 +151,14 @@ typedef struct mipt_scene_info {
 /* Device-side counters and timings of one mipt_frame_accumulate call. */
 typedef struct mipt_stats {
     uint64_t closest_rays;           /* closest-hit queries issued */
-    uint64_t shadow_rays;            /* any-hit queries issued */
+    uint64_t shadow_rays;            /* any-hit queries traced */
     uint64_t node_visits;            /* BVH nodes fetched (both kinds of query) */
     uint64_t triangle_tests;         /* ray/triangle tests executed */
     uint64_t closest_node_visits;
     uint64_t closest_triangle_tests;
     uint64_t active_pixels;          /* pixels of this shard whose primary ray hit */
-    uint64_t reserved0;
+    uint64_t shadow_rays_culled;     /* any-hit queries of the reference algorithm (CPUPathTracer.cpp:402) that were not traced:
+                                        the direct term they guard is +0 whatever the answer */
     double   closest_ms;             /* summed HIP-event time of the closest-hit kernel launches */
     double   shadow_ms;              /* ... of the any-hit kernel launches */
     double   shade_ms;               /* ... of ray generation, shading and resolve kernels */

@@ -34,7 +34,7 @@ def test_cornell_direct_golden_480x270(gpu, cornell):
     assert rel_err(img, g["bgr255"]).max() <= REL_TOL
     assert np.array_equal(img, g["bgr255"])                 # the arithmetic is the same fp32 sequence
     assert np.array_equal(host.pack_bgra(img).reshape(270, 480), g["dword"])
-    assert st.closest_rays == 480 * 270 and st.shadow_rays == int((ids >= 0).sum())
+    assert st.closest_rays == 480 * 270 and st.shadow_rays + st.shadow_rays_culled == int((ids >= 0).sum())
 
 
 def test_cornell_direct_full_resolution(gpu, cornell, cornell_oracle):
@@ -81,7 +81,7 @@ def test_cornell_gi_against_oracle(gpu, cornell, cornell_oracle):
     print(f"cornell GI N=16: rmse={rmse:.4g} |dmean|={dmean:.4g} sigma={sigma:.4g} identical={same:.4f}")
     assert dmean <= 3 * sigma
     assert rmse < 1.0              # same random stream: only sin/cos rounding separates the two sides
-    assert st.closest_rays + st.shadow_rays <= ids.size * (2 + 6 * 16)
+    assert st.closest_rays + st.shadow_rays + st.shadow_rays_culled <= ids.size * (2 + 6 * 16)
     assert st.closest_rays > ids.size
 
 
@@ -232,7 +232,7 @@ def test_headline_frame_at_full_size(gpu):
     npx = 1920 * 1080
     full = host.default_params(sun_pos=sun, global_illumination=1, num_samples=128)
     ref, ids, st = sc.render(cam, full)
-    assert st.closest_rays + st.shadow_rays > 1.2e9 and st.samples_done == 128
+    assert st.closest_rays + st.shadow_rays + st.shadow_rays_culled > 1.2e9 and st.samples_done == 128
     assert np.isfinite(ref).all() and ref.min() >= 0 and ref.max() <= 255
     assert (ids >= 0).mean() > 0.9
     # smaller passes: same image
@@ -278,7 +278,7 @@ def test_tile_shards_that_finalize_their_own_pixels(gpu, cornell):
         assert not ((total != 0).any(axis=2) & (img != 0).any(axis=2)).any()
         total += img
         ids = np.maximum(ids, sid)
-        rays += st.closest_rays + st.shadow_rays
+        rays += st.closest_rays + st.shadow_rays + st.shadow_rays_culled
     assert np.array_equal(total, ref) and np.array_equal(ids, ref_ids)
     # no duplicated work beyond the rays that leave the scene at once
-    assert rays <= st_full.closest_rays + st_full.shadow_rays + 4 * npx
+    assert rays <= st_full.closest_rays + st_full.shadow_rays + st_full.shadow_rays_culled + 4 * npx
