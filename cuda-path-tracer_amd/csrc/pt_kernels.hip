@@ -19,6 +19,17 @@
 // queue entries a wave of a shading kernel handles per reservation in its output queues
 #define SHADE_ITEMS 16
 
+// Streaming store: the ray queues and path states are written once and read once by a later
+// kernel; marking the stores non-temporal keeps them from displacing the shading records and
+// texels, which are gathered again and again, from the caches (bounce shading -5 %; the same
+// mark on the loads of queue entries made the traversal slower).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4* p, float4 v)
+{
+    v4f_t x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(x, (v4f_t*)p);
+}
+
 // ---------------------------------------------------------------------------------------
 // k_raygen: CPUPathTracer.cpp:489-497 (the CPU flavour transforms (vx,vy,1) first and
 // normalises once; XMVector3TransformCoord/Normal evaluate ((z*r2 [+ r3]) + y*r1) + x*r0)
@@ -146,7 +157,7 @@ __device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32
     return h ? __float_as_uint(t0) : KEY_MISS;
 }
 
-template <int MODE>
+template <int MODE, bool BLOCKS>
 __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
@@ -181,16 +192,24 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
         // ---- hand rays to idle lanes
         unsigned long long idleMask = __ballot(cur == LANE_IDLE);
         if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
-            // a queue in blocks can hold reservations without a valid entry: a few more are tried at once
-            for (int tries = 0; tries < 4 && rangeNext >= rangeEnd && !queueDry; tries++) {
-                int b = 0;
-                if (lane == 0) b = atomicAdd(head, chunk);
-                b = __builtin_amdgcn_readfirstlane(b);
-                if (b >= n) { queueDry = true; break; }
-                int end = n;
-                if (blockCount) end = ((b >> MIPT_QBLOCK_SHIFT) << MIPT_QBLOCK_SHIFT) + blockCount[b >> MIPT_QBLOCK_SHIFT];
-                rangeNext = b; rangeEnd = (b + chunk < end) ? b + chunk : end;
-                if (!blockCount) break;
+            if (!BLOCKS) {
+                if (rangeNext >= rangeEnd) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(head, chunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= n) queueDry = true;
+                    else { rangeNext = b; rangeEnd = (b + chunk < n) ? b + chunk : n; }
+                }
+            } else {
+                // a reservation in a queue in blocks can be without a valid entry: a few more are tried at once
+                for (int tries = 0; tries < 4 && rangeNext >= rangeEnd && !queueDry; tries++) {
+                    int b = 0;
+                    if (lane == 0) b = atomicAdd(head, chunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= n) { queueDry = true; break; }
+                    int end = ((b >> MIPT_QBLOCK_SHIFT) << MIPT_QBLOCK_SHIFT) + blockCount[b >> MIPT_QBLOCK_SHIFT];
+                    rangeNext = b; rangeEnd = (b + chunk < end) ? b + chunk : end;
+                }
             }
             int avail = rangeEnd - rangeNext;
             if (avail > 0) {
@@ -389,7 +408,7 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit)
 {
     size_t smem = trace_smem(S);
-    hipLaunchKernelGGL(k_trace<0>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
+    hipLaunchKernelGGL((k_trace<0, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
                        (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0);
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
@@ -399,14 +418,18 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const 
     size_t smem = trace_smem(S);
     int chunk = trace_chunk();
     if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK;   // must divide a block
-    hipLaunchKernelGGL(k_trace<1>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
-                       (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
+    if (d_blockCount)
+        hipLaunchKernelGGL((k_trace<1, true>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
+                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
+    else
+        hipLaunchKernelGGL((k_trace<1, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
+                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     size_t smem = trace_smem(S);
-    hipLaunchKernelGGL(k_trace<2>, dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
+    hipLaunchKernelGGL((k_trace<2, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
                        (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
 }
 
@@ -478,11 +501,23 @@ __device__ __forceinline__ uint32_t fetch_texel_bgr(const DevScene& S, int fmt, 
     return ((uint32_t)f[0] & 255u) | (((uint32_t)f[1] & 255u) << 8) | (((uint32_t)f[2] & 255u) << 16);
 }
 
-__device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender& R, int tri, float ua, float va)
+// the part of a shading record every hit needs, fetched ahead of its use by bounce shading
+struct ShadeRec { float4 r0, r1, r2, r3, r4, tex; const float4* a; };
+
+__device__ __forceinline__ ShadeRec load_shade_rec(const DevScene& S, const DevRender& R, int tri)
+{
+    ShadeRec c;
+    c.a = S.shade + (size_t)tri * MIPT_SHADE_F4;
+    c.r0 = c.a[0]; c.r1 = c.a[1]; c.r2 = c.a[2]; c.r3 = c.a[3]; c.r4 = c.a[4];
+    c.tex = R.useTextures ? c.a[5] : make_float4(0, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender& R, const ShadeRec& c, float ua, float va)
 {
     Surface sf;
-    const float4* a = S.shade + (size_t)tri * MIPT_SHADE_F4;
-    float4 r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4];
+    const float4* a = c.a;
+    const float4 r0 = c.r0, r1 = c.r1, r2 = c.r2, r3 = c.r3, r4 = c.r4;
     float w = 1 - ua - va;
     float u = w * r3.y + ua * r3.w + va * r4.y;          // :231 uses tex.y
     float v = w * r3.x + ua * r3.z + va * r4.x;          // :232 uses tex.x
@@ -496,7 +531,7 @@ __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender
     int texFmt = MIPT_TEXFMT_NONE, nmlFmt = MIPT_TEXFMT_NONE;
     uint64_t texOff = 0, nmlOff = 0;
     if (R.useTextures) {
-        float4 t = a[5];
+        float4 t = c.tex;
         texOff = (uint64_t)__float_as_uint(t.x) | ((uint64_t)__float_as_uint(t.y) << 32);
         texW = (long)(__float_as_uint(t.z) & 0x3fffffffu); texFmt = (int)(__float_as_uint(t.z) >> 30); texH = __float_as_int(t.w);
     }
@@ -579,7 +614,7 @@ __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, 
     bool wantShadow = false;
     if (inRange) triIdImage[p] = tri;
     if (isHit) {
-        Surface sf = surface_at(S, R, tri, h.y, h.z);
+        Surface sf = surface_at(S, R, load_shade_rec(S, R, tri), h.y, h.z);
         float D = direct_term(R, sf, so, sd);
         wantShadow = shadow_matters(D);
         pixState[(size_t)p * 4 + 0] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
@@ -677,16 +712,28 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             nbase = __builtin_amdgcn_readfirstlane(nbase);
         }
         int running = 0, shadowRun = 0;
+        // The chain hit record -> shading record -> texel is three dependent fetches, the last two of
+        // them gathers; the kernel is bound by their latency.  The hit record is therefore fetched two
+        // items ahead and the shading record one item ahead of the item that is being shaded.
+        const float4 noHit = make_float4(0, 0, 0, __int_as_float(-1));
+        auto load_hit = [&](int k) { int64_t i = first + k * WAVE + lane; return (k < SHADE_ITEMS && i < n) ? hit[i] : noHit; };
+        float4 hNext = load_hit(0), hNext2 = load_hit(1);
+        ShadeRec recNext = {};
+        if (__float_as_int(hNext.w) >= 0) recNext = load_shade_rec(S, R, __float_as_int(hNext.w));
         for (int k = 0; k < SHADE_ITEMS; k++) {
             int64_t i = first + k * WAVE + lane;
             bool inRange = i < n;
-            float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
+            const float4 h = hNext;
+            const ShadeRec rec = recNext;
+            hNext = hNext2;
+            hNext2 = load_hit(k + 2);
+            if (__float_as_int(hNext.w) >= 0) recNext = load_shade_rec(S, R, __float_as_int(hNext.w));
             int tri = __float_as_int(h.w);
             bool isHit = inRange && tri >= 0;
             // a ray that left the scene ends its path: the state of this level is zero.  Every slot that
             // reaches a level is written here, hit or miss, so the buffer needs no clearing between passes
             // (levels a path did not reach are multiplied by the zero albedo of the level where it ended)
-            if (inRange && !isHit) pathState[(size_t)(level - 1) * slotsPerLevel + __float_as_int(h.x)] = make_float4(0, 0, 0, 0);
+            if (inRange && !isHit) store_stream(&pathState[(size_t)(level - 1) * slotsPerLevel + __float_as_int(h.x)], make_float4(0, 0, 0, 0));
             unsigned long long mask = __ballot(isHit);
             if (mask == 0) continue;
             int prefix = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -697,25 +744,25 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
             F3 so = f3(0, 0, 0), sd = f3(0, 0, 0);
             if (isHit) {
                 slot = __float_as_int(h.x);               // the traversal put the ray's slot id where the distance would be
-                Surface sf = surface_at(S, R, tri, h.y, h.z);
+                Surface sf = surface_at(S, R, rec, h.y, h.z);
                 float D = direct_term(R, sf, so, sd);
                 wantShadow = shadow_matters(D);
-                pathState[(size_t)(level - 1) * slotsPerLevel + slot] = make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z);
+                store_stream(&pathState[(size_t)(level - 1) * slotsPerLevel + slot], make_float4(D, sf.albedo.x, sf.albedo.y, sf.albedo.z));
                 if (spawnLevel) {
                     int a = slot % nAct, s = slot / nAct;
                     uint32_t p = (uint32_t)actPix[a], smp = (uint32_t)(n0 + s);
                     float r1 = rng_u01(R.seed, p, smp, (uint32_t)level, 0), r2 = rng_u01(R.seed, p, smp, (uint32_t)level, 1);
                     F3 nd = to_world(sample_hemisphere(r1, r2), sf.N, sf.Nt, sf.Nb);
                     F3 no = f3add(sf.hp, f3scale(nd, PT_BIAS));
-                    nextQ.o[nbase + idx] = make_float4(no.x, no.y, no.z, __int_as_float(slot));
-                    nextQ.d[nbase + idx] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                    store_stream(&nextQ.o[nbase + idx], make_float4(no.x, no.y, no.z, __int_as_float(slot)));
+                    store_stream(&nextQ.d[nbase + idx], make_float4(nd.x, nd.y, nd.z, 0.0f));
                 }
             }
             unsigned long long smask = __ballot(wantShadow);
             if (wantShadow) {
                 int64_t si = first + shadowRun + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(smask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smask, 0u));
-                shadowQ.o[si] = make_float4(so.x, so.y, so.z, __int_as_float(slot));
-                shadowQ.d[si] = make_float4(sd.x, sd.y, sd.z, __int_as_float(level));
+                store_stream(&shadowQ.o[si], make_float4(so.x, so.y, so.z, __int_as_float(slot)));
+                store_stream(&shadowQ.d[si], make_float4(sd.x, sd.y, sd.z, __int_as_float(level)));
             }
             shadowRun += __popcll(smask);
         }
