@@ -133,6 +133,12 @@ def main():
     # (disjoint pixels: exact); sample shards: the unclamped sums are added and rank 0 finalizes
     own_tiles = world > 1 and args.shard == "tiles"
     shard = sharding.shard_fields(rank, world, samples, args.shard, own_pixels_only=own_tiles)
+    # MIPT_BENCH_AS_SHARD=r/N (single process only): time the work of rank r of an N-rank run alone, to see how
+    # the per-rank frame time falls with N where only one GPU is at hand
+    if world == 1 and os.environ.get("MIPT_BENCH_AS_SHARD"):
+        r_, n_ = (int(x) for x in os.environ["MIPT_BENCH_AS_SHARD"].split("/"))
+        own_tiles = args.shard == "tiles"
+        shard = sharding.shard_fields(r_, n_, samples, args.shard, own_pixels_only=own_tiles)
     params = host.default_params(sun_pos=sun, global_illumination=gi, num_samples=samples, use_textures=1, use_normals=0,
                                  chunk_samples=args.chunk, **shard)
     frame = device.Frame(dev, cam, params)
