@@ -26,7 +26,7 @@ if len(sys.argv) > 3:
     import json
     out, workload = sys.argv[2], sys.argv[3]
     for r in rows:
-        if "k_trace<0>" in r["kernel"]:
+        if "k_trace<0" in r["kernel"]:
             calls = float(r["calls"])
             fetch, write = float(r["FETCH_SIZE"]) * 1024, float(r["WRITE_SIZE"]) * 1024
             try:
