@@ -100,6 +100,27 @@ def test_atrium_gi_against_oracle(gpu, atrium_small, atrium_small_oracle):
     assert abs(int(st.closest_rays) - int(ost.closest_rays)) <= 0.001 * ost.closest_rays
 
 
+def test_shadow_rays_that_cannot_matter_are_counted_not_traced(gpu, atrium_small, atrium_small_oracle):
+    """The reference casts a shadow ray at every hit (CPUPathTracer.cpp:402); where the direct term is +0
+    the library skips the traversal.  traced + culled must equal the oracle's shadow-ray count, and with a
+    dark sun (intensity 0: every direct term is +0) no shadow ray is traced at all, every block of the
+    shadow queue is empty, and the image still equals the oracle's."""
+    cam, sun = scenes.crytek_camera(div=8)
+    sc = gpu.Scene(atrium_small.desc)
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=4)
+    img, ids, st = sc.render(cam, prm)
+    oimg, _, otri, ost = atrium_small_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids, otri)
+    assert st.shadow_rays_culled > 0 and st.shadow_rays > 0
+    assert abs(int(st.shadow_rays + st.shadow_rays_culled) - int(ost.shadow_rays)) <= 0.001 * ost.shadow_rays
+    dark = host.default_params(sun_pos=sun, global_illumination=1, num_samples=4, sun_intensity=0.0)
+    img, ids, st = sc.render(cam, dark)
+    oimg, _, otri, ost = atrium_small_oracle.render(cam, dark, accel=ob.ACCEL_BRUTE)
+    assert st.shadow_rays == 0 and st.shadow_rays_culled > 0
+    assert np.array_equal(ids, otri)
+    assert not img.any() and not oimg.any()         # no light, no colour: L_k = (0 + 0 * ...) * A / pi
+
+
 def test_pass_size_does_not_change_the_image(gpu, cornell):
     cam, sun = scenes.cornell_camera(div=8)
     sc = gpu.Scene(cornell.desc)
