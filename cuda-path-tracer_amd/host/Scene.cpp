@@ -458,6 +458,47 @@ HostScene* BuildInstanced(const HostScene& base, int copies, float spacing)
 }
 
 // ---------------------------------------------------------------------------------
+// PNG encoding on top of zlib: IHDR, one IDAT, IEND
+static void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+static void put_chunk(std::vector<uint8_t>& file, const char* type, const std::vector<uint8_t>& data)
+{
+	put32(file, (uint32_t)data.size());
+	size_t start = file.size();
+	file.insert(file.end(), type, type + 4);
+	file.insert(file.end(), data.begin(), data.end());
+	put32(file, (uint32_t)crc32(0, &file[start], (uInt)(file.size() - start)));
+}
+
+bool WritePng(const char* path, const std::vector<uint32_t>& bgra, int32_t width, int32_t height)
+{
+	if (width <= 0 || height <= 0 || bgra.size() < (size_t)width * height) return false;
+	std::vector<uint8_t> raw(((size_t)width * 3 + 1) * height);
+	for (int32_t y = 0; y < height; y++) {
+		uint8_t* row = &raw[((size_t)width * 3 + 1) * y];
+		row[0] = 0;                                   // filter type: none
+		for (int32_t x = 0; x < width; x++) {
+			uint32_t t = bgra[(size_t)y * width + x];
+			row[1 + 3 * x] = (uint8_t)(t >> 16); row[2 + 3 * x] = (uint8_t)(t >> 8); row[3 + 3 * x] = (uint8_t)t;
+		}
+	}
+	uLongf clen = compressBound((uLong)raw.size());
+	std::vector<uint8_t> comp(clen);
+	if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+	comp.resize(clen);
+	std::vector<uint8_t> file = { 137, 80, 78, 71, 13, 10, 26, 10 };
+	std::vector<uint8_t> ihdr;
+	put32(ihdr, (uint32_t)width); put32(ihdr, (uint32_t)height);
+	ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit RGB, no interlace
+	put_chunk(file, "IHDR", ihdr);
+	put_chunk(file, "IDAT", comp);
+	put_chunk(file, "IEND", {});
+	FILE* f = fopen(path, "wb");
+	if (!f) return false;
+	bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+	fclose(f);
+	return ok;
+}
+
 // PNG decoding on top of zlib
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 

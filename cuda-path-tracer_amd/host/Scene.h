@@ -60,6 +60,8 @@ HostScene* BuildInstanced(const HostScene& base, int copies, float spacing);
 bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
 // baseline JPEG (Jpeg.cpp); same texel layout
 bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
+// 8-bit RGB PNG from BGRA8 DWORDs (alpha dropped), zlib-compressed, filter type 0
+bool WritePng(const char* path, const std::vector<uint32_t>& bgra, int32_t width, int32_t height);
 // PNG or JPEG by the file's first bytes
 bool LoadImageFile(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height);
 

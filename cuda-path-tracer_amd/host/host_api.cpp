@@ -136,6 +136,54 @@ int mipt_host_write_ppm(const char* path, const float* bgr255, int32_t width, in
 	return MIPT_OK;
 }
 
+int mipt_host_write_png(const char* path, const float* bgr255, int32_t width, int32_t height)
+{
+	if (!path || !bgr255 || width <= 0 || height <= 0) return MIPT_E_INVALID;
+	std::vector<uint32_t> px((size_t)width * height);
+	mipt_host_pack_bgra(bgr255, (int64_t)px.size(), px.data());
+	return WritePng(path, px, width, height) ? MIPT_OK : MIPT_E_INVALID;
+}
+
+int mipt_host_compare_images(const float* a, const float* b, int64_t n, mipt_host_image_diff* out)
+{
+	if (!a || !b || !out || n <= 0) return MIPT_E_INVALID;
+	double se = 0, mx = 0, sa = 0, sb = 0, sbb = 0; int64_t same = 0;
+	for (int64_t i = 0; i < n; i++) {
+		double d = (double)a[i] - (double)b[i];
+		se += d * d; if (fabs(d) > mx) mx = fabs(d);
+		sa += a[i]; sb += b[i]; sbb += (double)b[i] * b[i];
+		same += a[i] == b[i];
+	}
+	double mb = sb / n, var = sbb / n - mb * mb;
+	out->rmse = sqrt(se / n); out->max_abs = mx; out->mean_diff = fabs(sa / n - mb);
+	out->sigma = sqrt((var > 0 ? var : 0) / n); out->identical = (double)same / n;
+	return MIPT_OK;
+}
+
+int mipt_host_read_image_bgr255(const char* path, float** out, int32_t* width, int32_t* height)
+{
+	if (!path || !out || !width || !height) return MIPT_E_INVALID;
+	*out = nullptr;
+	std::vector<uint32_t> px; int32_t w = 0, h = 0;
+	FILE* f = fopen(path, "rb");
+	if (!f) return MIPT_E_INVALID;
+	int maxv = 0;
+	bool ppm = fscanf(f, "P6 %d %d %d", &w, &h, &maxv) == 3 && maxv == 255 && w > 0 && h > 0 && fgetc(f) != EOF;
+	if (ppm) {
+		std::vector<unsigned char> rgb((size_t)w * h * 3);
+		ppm = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+		px.resize((size_t)w * h);
+		for (size_t i = 0; ppm && i < px.size(); i++) px[i] = (uint32_t)rgb[3 * i + 2] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i] << 16) | 0xff000000u;
+	}
+	fclose(f);
+	if (!ppm && !LoadImageFile(path, px, w, h)) return MIPT_E_INVALID;
+	float* p = (float*)malloc(sizeof(float) * 3 * px.size());
+	if (!p) return MIPT_E_NOMEM;
+	for (size_t i = 0; i < px.size(); i++) { p[3 * i] = (float)(px[i] & 255u); p[3 * i + 1] = (float)((px[i] >> 8) & 255u); p[3 * i + 2] = (float)((px[i] >> 16) & 255u); }
+	*out = p; *width = w; *height = h;
+	return MIPT_OK;
+}
+
 int mipt_host_load_png(const char* path, uint32_t** out, int32_t* width, int32_t* height)
 {
 	std::vector<uint32_t> px; int32_t w = 0, h = 0;

@@ -4,7 +4,7 @@
 //
 //   pt_headless --scene cornell|sponza|crytek [--obj file.mesh] [--tris N] [--tex N]
 //               [--samples N] [--gi 0|1] [--textures 0|1] [--normals 0|1] [--div 1|2|4]
-//               [--width W --height H] [--out image.ppm]
+//               [--width W --height H] [--out image.ppm|image.png]
 #include "../../include/PathTracer.h"
 #include "../../include/PTProgress.h"
 #include "../../include/mipt_host.h"
@@ -87,7 +87,10 @@ int main(int argc, char** argv)
 		float3{ sun[0], sun[1], sun[2] }, float3{ 0, 1, 0 }, 3.0f, gi, textures, normals, meshes.data(), (long)meshes.size(), mats.data(), (long)mats.size());
 	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	fprintf(stderr, "rendered %ldx%ld in %.3f s\n", W, H, sec);
-	mipt_host_write_ppm(out.c_str(), (const float*)image.data(), (int32_t)W, (int32_t)H);
+	if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0)
+		mipt_host_write_png(out.c_str(), (const float*)image.data(), (int32_t)W, (int32_t)H);
+	else
+		mipt_host_write_ppm(out.c_str(), (const float*)image.data(), (int32_t)W, (int32_t)H);
 	mipt_host_scene_free(hs);
 	return 0;
 }

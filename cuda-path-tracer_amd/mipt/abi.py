@@ -85,9 +85,15 @@ MIPT_SYMBOLS = [
     "mipt_device_synchronize",
 ]
 # every symbol include/mipt_host.h declares
+class ImageDiff(C.Structure):
+    _fields_ = [("rmse", C.c_double), ("max_abs", C.c_double), ("mean_diff", C.c_double), ("sigma", C.c_double),
+                ("identical", C.c_double)]
+
+
 MIPT_HOST_SYMBOLS = [
     "mipt_host_scene_load_obj", "mipt_host_scene_atrium", "mipt_host_scene_instanced", "mipt_host_scene_free",
     "mipt_host_scene_desc", "mipt_host_scene_label", "mipt_host_camera_preset", "mipt_host_camera_make",
-    "mipt_host_default_params", "mipt_host_pack_bgra", "mipt_host_write_ppm", "mipt_host_load_png", "mipt_host_load_image",
+    "mipt_host_default_params", "mipt_host_pack_bgra", "mipt_host_write_ppm", "mipt_host_write_png", "mipt_host_compare_images",
+    "mipt_host_read_image_bgr255", "mipt_host_load_png", "mipt_host_load_image",
     "mipt_host_free",
 ]

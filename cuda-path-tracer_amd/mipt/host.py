@@ -35,6 +35,10 @@ def lib():
         L.mipt_host_default_params.argtypes = [C.POINTER(abi.Params)]
         L.mipt_host_pack_bgra.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.mipt_host_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mipt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mipt_host_compare_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(abi.ImageDiff)]
+        L.mipt_host_read_image_bgr255.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32),
+                                                  C.POINTER(C.c_int32)]
         L.mipt_host_load_png.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mipt_host_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mipt_host_free.argtypes = [C.c_void_p]
@@ -133,6 +137,37 @@ def pack_bgra(bgr255):
 def write_ppm(path, bgr255, width, height):
     a = np.ascontiguousarray(bgr255, dtype=np.float32)
     return lib().mipt_host_write_ppm(os.fsencode(path), a.ctypes.data, width, height)
+
+
+def write_png(path, bgr255, width, height):
+    a = np.ascontiguousarray(bgr255, dtype=np.float32)
+    return lib().mipt_host_write_png(os.fsencode(path), a.ctypes.data, width, height)
+
+
+def compare_images(a, b):
+    """rmse, max_abs, mean_diff, sigma, identical of two float 255*rgb images (mipt_host_compare_images)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    if a.size != b.size:
+        raise ValueError("images differ in size")
+    d = abi.ImageDiff()
+    rc = lib().mipt_host_compare_images(a.ctypes.data, b.ctypes.data, C.c_int64(a.size), C.byref(d))
+    if rc != 0:
+        raise ValueError("mipt_host_compare_images failed")
+    return d
+
+
+def read_image(path):
+    """Image file (PPM of this library, PNG, baseline JPEG) -> float32 array (height, width, 3), BGR, 0..255."""
+    out = C.POINTER(C.c_float)()
+    w, h = C.c_int32(), C.c_int32()
+    rc = lib().mipt_host_read_image_bgr255(os.fsencode(path), C.byref(out), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise OSError(f"cannot read image {path}")
+    try:
+        return np.ctypeslib.as_array(out, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().mipt_host_free(out)
 
 
 def load_png(path):

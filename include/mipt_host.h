@@ -64,6 +64,21 @@ void mipt_host_default_params(mipt_params* p);
  * or 24-bit BGR rows as RayTracerView.cpp:925-931. */
 void mipt_host_pack_bgra(const float* bgr255, int64_t num_pixels, uint32_t* out);
 int mipt_host_write_ppm(const char* path, const float* bgr255, int32_t width, int32_t height);
+/* The same bytes as a PNG file (8-bit RGB, no alpha); stands in for CImage::Save,
+ * RayTracerView.cpp:934,1032. */
+int mipt_host_write_png(const char* path, const float* bgr255, int32_t width, int32_t height);
+
+/* Comparison of two images of the same size given as float 255*rgb arrays (num_values = 3 * pixels):
+ * root mean square error, largest absolute difference, difference of the means, the standard error
+ * of the mean of `b` taken over its values (sigma = std / sqrt(num_values)) and the share of values
+ * that are identical.  A Monte Carlo image agrees with its reference when mean_diff <= 3 * sigma. */
+typedef struct mipt_host_image_diff {
+    double rmse, max_abs, mean_diff, sigma, identical;
+} mipt_host_image_diff;
+int mipt_host_compare_images(const float* a, const float* b, int64_t num_values, mipt_host_image_diff* out);
+/* Reads an image file written by this library (binary PPM) or any PNG / baseline JPEG into float
+ * 255*rgb values in BGR order; *out is malloc'ed, release with mipt_host_free. */
+int mipt_host_read_image_bgr255(const char* path, float** out, int32_t* width, int32_t* height);
 
 /* Decodes a PNG file to BGRA8 DWORD texels (byte0 = blue), the layout MainFrm.cpp:262-269
  * produces through CImage.  *out is malloc'ed; release with mipt_host_free. */

@@ -213,3 +213,42 @@ def test_obj_material_with_jpeg_texture(tmp_path):
     tex = np.ctypeslib.as_array(C.cast(m.tex_data, C.POINTER(C.c_uint32)), shape=(4, 8))
     r, g, b = (tex >> 16) & 255, (tex >> 8) & 255, tex & 255
     assert abs(int(r[0, 0]) - 200) <= 2 and abs(int(g[0, 0]) - 100) <= 2 and abs(int(b[0, 0]) - 50) <= 2
+
+
+def test_png_writer_and_image_compare(tmp_path):
+    """The PNG written for an image decodes (by Pillow and by the library's own reader) to the truncated
+    bytes of the output stage; the PPM reads back the same; mipt_host_compare_images and pt_imgdiff
+    report the figures numpy computes."""
+    import subprocess
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    h, w = 23, 41
+    img = (rng.random((h, w, 3)) * 255.999).astype(np.float32)          # BGR, 0..255
+    png, ppm = tmp_path / "o.png", tmp_path / "o.ppm"
+    assert host.write_png(str(png), img, w, h) == 0
+    assert host.write_ppm(str(ppm), img, w, h) == 0
+    want_rgb = np.floor(img[..., ::-1]).astype(np.uint8)
+    assert np.array_equal(np.array(Image.open(png).convert("RGB")), want_rgb)
+    back = host.read_image(str(png))
+    assert back.shape == (h, w, 3) and np.array_equal(back, np.floor(img))
+    assert np.array_equal(host.read_image(str(ppm)), np.floor(img))
+    with pytest.raises(OSError):
+        host.read_image(str(tmp_path / "missing.png"))
+
+    other = np.clip(img + rng.normal(0, 2.0, img.shape).astype(np.float32), 0, 255)
+    d = host.compare_images(other, img)
+    diff = other.astype(np.float64) - img.astype(np.float64)
+    assert math.isclose(d.rmse, math.sqrt((diff ** 2).mean()), rel_tol=1e-9)
+    assert math.isclose(d.max_abs, np.abs(diff).max(), rel_tol=1e-9)
+    assert math.isclose(d.mean_diff, abs(other.astype(np.float64).mean() - img.astype(np.float64).mean()), rel_tol=1e-6, abs_tol=1e-9)
+    assert math.isclose(d.sigma, img.astype(np.float64).std() / math.sqrt(img.size), rel_tol=1e-6)
+    assert d.identical < 0.2 and host.compare_images(img, img).identical == 1.0
+
+    tool = os.path.join(os.path.dirname(host.HOST_LIB_PATH), "pt_imgdiff")
+    same = subprocess.run([tool, str(png), str(ppm)], capture_output=True, text=True)
+    assert same.returncode == 0 and "identical 1.0000" in same.stdout
+    host.write_png(str(tmp_path / "bright.png"), np.clip(img + 40, 0, 255), w, h)
+    differ = subprocess.run([tool, str(png), str(tmp_path / "bright.png")], capture_output=True, text=True)
+    assert differ.returncode == 1 and "differ" in differ.stdout
+    host.write_png(str(tmp_path / "small.png"), img[:5], w, 5)
+    assert subprocess.run([tool, str(png), str(tmp_path / "small.png")], capture_output=True).returncode == 1
