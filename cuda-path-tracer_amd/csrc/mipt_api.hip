@@ -599,6 +599,18 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         unsigned long long h[ST_COUNT];
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED];
+        if (R.ownPixelsOnly) {
+            // the stand-in rays of pixels that belong to other shards are no rays of the image: not counted
+            int64_t owned = 0;
+            const int tilesY = (R.H + R.tileSize - 1) / R.tileSize;
+            for (int ty = 0; ty < tilesY; ty++)
+                for (int tx = 0; tx < R.tilesX; tx++)
+                    if ((ty * R.tilesX + tx) % R.shardCount == R.shardRank) {
+                        int w = R.W - tx * R.tileSize, hgt = R.H - ty * R.tileSize;
+                        owned += (int64_t)(w < R.tileSize ? w : R.tileSize) * (hgt < R.tileSize ? hgt : R.tileSize);
+                    }
+            stats->closest_rays -= (uint64_t)((int64_t)P - owned);
+        }
 #ifdef MIPT_TRACE_PROFILE
         fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu\n",
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6]);
