@@ -180,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([
-        float(sum(s.closest_rays + s.shadow_rays + s.shadow_rays_culled for s in stats)),
+        float(sum(s.closest_rays + s.shadow_rays for s in stats)),
         float(sum(s.closest_triangle_tests for s in stats)), float(sum(s.closest_node_visits for s in stats)),
         float(sum(s.closest_ms for s in stats)), float(sum(s.closest_launches for s in stats)),
         float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
@@ -218,10 +218,12 @@ def main():
                 "materials": int(info.num_materials), "image": f"{cam.image_size[0]}x{cam.image_size[1]}",
                 "samples": samples, "global_illumination": bool(gi), "textures": True, "normal_maps": False,
                 "parallelism": f"{args.shard}x{world}", "rays_per_frame": total_rays / args.steps,
-                # rays_per_frame counts the rays the reference algorithm casts for this frame (one closest-hit and one
-                # shadow query per path vertex); shadow queries whose answer cannot change the image are answered
-                # without a traversal and are listed here
+                # `value` counts the rays that were traversed.  The reference casts a shadow ray at every hit; the
+                # ones whose answer cannot change the image (direct term +0) are not traversed here.  With them the
+                # frame has reference_rays_per_frame rays, the number an implementation that traces all of them reports.
                 "shadow_rays_not_traversed_per_frame": culled_rays / args.steps,
+                "reference_rays_per_frame": (total_rays + culled_rays) / args.steps,
+                "reference_mrays_per_s": (total_rays + culled_rays) / elapsed / 1e6,
                 "render_time_s": elapsed / args.steps, "bvh_build_ms": info.build_ms, "bvh_depth": int(info.max_depth),
                 "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "image_sha1": image_sha1, "samples_per_pass": int(s0.chunk_samples),
             },
