@@ -20,6 +20,23 @@ static thread_local std::string g_err;
 static int g_device = -1;
 static int g_numCUs = 256;
 
+// Work memory of mipt_trace_rays_device, the entry point that allocates nothing: ray queue, hit
+// records, queue counters and statistics of one call.  The array is part of the code object, so
+// every GPU the library runs on holds its own copy, at its own address, until the process ends.
+// In host code the name is only a handle for hipGetSymbolAddress: g_scratchPtr[device] is the
+// address kernels and memsets are given.
+#define SCRATCH_RAYS   MIPT_TRACE_DEVICE_MAX_RAYS
+#define SCRATCH_Q_O    0
+#define SCRATCH_Q_D    (SCRATCH_Q_O + 16 * (size_t)SCRATCH_RAYS)
+#define SCRATCH_HIT    (SCRATCH_Q_D + 16 * (size_t)SCRATCH_RAYS)
+#define SCRATCH_CTR    (SCRATCH_HIT + 16 * (size_t)SCRATCH_RAYS)      /* 4 x int32: count, closest head, any-hit head, unused */
+#define SCRATCH_STATS  (SCRATCH_CTR + 256)
+#define SCRATCH_BYTES  (SCRATCH_STATS + 256)
+static_assert(8 * ST_COUNT <= 256, "statistics slots must fit their part of the scratch");
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+#define MIPT_MAX_DEVICES 64
+static unsigned char* g_scratchPtr[MIPT_MAX_DEVICES];
+
 static int fail(int code, const char* fmt, ...)
 {
     char buf[512];
@@ -82,6 +99,12 @@ int mipt_init(int32_t device)
     hipDeviceProp_t prop;
     HIPTRY(hipGetDeviceProperties(&prop, device));
     g_numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (device < MIPT_MAX_DEVICES && !g_scratchPtr[device]) {
+        // this device's copy of the scratch array (the device is current here)
+        void* p = nullptr;
+        HIPTRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratchPtr[device] = (unsigned char*)p;
+    }
     g_device = device;
     return MIPT_OK;
 }
@@ -349,6 +372,29 @@ int mipt_scene_download_bvh(const mipt_scene* s, uint32_t* nodes, float* v0, flo
 }
 
 // ---------------------------------------------------------------------------------------
+// The two queries of mipt_trace_rays over rays in device memory, with every buffer given: the ray
+// queue q and the hit records (numRays entries each), ctr and stats (256 bytes each: 4 x int32 and ST_COUNT x uint64 at their start).
+// Results go to device arrays.  Enqueues on the scene's stream and waits for it.
+static hipError_t trace_device(mipt_scene* s, const float* dRays, int64_t n, float eps, RayQueue q, float4* hit, int32_t* ctr,
+                               unsigned long long* stats, int32_t* dTri, float* dTuv, uint8_t* dAny)
+{
+    hipError_t e = hipSuccess;
+    auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    tryq(hipMemsetAsync(ctr, 0, 256, s->stream));
+    tryq(hipMemsetAsync(stats, 0, 256, s->stream));
+    if (e != hipSuccess) return e;
+    launch_set_i32(ctr, (int32_t)n, s->stream);
+    launch_pack_rays(dRays, n, q, s->stream);
+    if (dTri || dTuv) {
+        launch_closest(s->dev, q, ctr, (int32_t)n, ctr + 1, hit, eps, stats, g_numCUs, s->stream);
+        launch_unpack_hits(hit, n, dTri, dTuv, s->stream);
+    }
+    if (dAny) launch_anyhit_flags(s->dev, q, ctr, (int32_t)n, ctr + 2, dAny, eps, stats, g_numCUs, s->stream);
+    tryq(hipStreamSynchronize(s->stream));
+    tryq(hipGetLastError());
+    return e;
+}
+
 int mipt_trace_rays(mipt_scene* s, const float* rays, int64_t n, float eps, int32_t* outTri, float* outTuv, uint8_t* outAny)
 {
     if (!s || (n > 0 && !rays)) return fail(MIPT_E_INVALID, "null argument");
@@ -357,35 +403,45 @@ int mipt_trace_rays(mipt_scene* s, const float* rays, int64_t n, float eps, int3
     int rc = ensure_init();
     if (rc) return rc;
     float* dRays = nullptr; RayQueue q = {}; float4* hit = nullptr; uint8_t* flags = nullptr; int32_t* ctr = nullptr;
+    int32_t* dTri = nullptr; float* dTuv = nullptr;
     unsigned long long* stats = nullptr;
     hipError_t e = hipSuccess;
-    std::vector<float4> hHit;
     auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     tryq(hipMalloc(&dRays, 24 * (size_t)n)); tryq(hipMalloc(&q.o, 16 * (size_t)n)); tryq(hipMalloc(&q.d, 16 * (size_t)n));
-    tryq(hipMalloc(&hit, 16 * (size_t)n)); tryq(hipMalloc(&flags, (size_t)n)); tryq(hipMalloc(&ctr, 16)); tryq(hipMalloc(&stats, 8 * ST_COUNT));
+    tryq(hipMalloc(&hit, 16 * (size_t)n)); tryq(hipMalloc(&ctr, 256)); tryq(hipMalloc(&stats, 256));
+    if (outAny) tryq(hipMalloc(&flags, (size_t)n));
+    if (outTri) tryq(hipMalloc(&dTri, 4 * (size_t)n));
+    if (outTuv) tryq(hipMalloc(&dTuv, 12 * (size_t)n));
     if (e == hipSuccess) {
-        int32_t hc[4] = { (int32_t)n, 0, 0, 0 };
         tryq(hipMemcpy(dRays, rays, 24 * (size_t)n, hipMemcpyHostToDevice));
-        tryq(hipMemcpy(ctr, hc, 16, hipMemcpyHostToDevice));
-        tryq(hipMemset(stats, 0, 8 * ST_COUNT));
-        launch_pack_rays(dRays, n, q, s->stream);
-        if (outTri || outTuv) launch_closest(s->dev, q, ctr, (int32_t)n, ctr + 1, hit, eps, stats, g_numCUs, s->stream);
-        if (outAny) launch_anyhit_flags(s->dev, q, ctr, (int32_t)n, ctr + 2, flags, eps, stats, g_numCUs, s->stream);
-        tryq(hipStreamSynchronize(s->stream));
-        tryq(hipGetLastError());
-        if (e == hipSuccess && (outTri || outTuv)) {
-            hHit.resize((size_t)n);
-            tryq(hipMemcpy(hHit.data(), hit, 16 * (size_t)n, hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < n && e == hipSuccess; i++) {
-                int32_t tri; memcpy(&tri, &hHit[(size_t)i].w, 4);
-                if (outTri) outTri[i] = tri;
-                if (outTuv) { outTuv[3 * i] = tri >= 0 ? hHit[(size_t)i].x : 0; outTuv[3 * i + 1] = tri >= 0 ? hHit[(size_t)i].y : 0; outTuv[3 * i + 2] = tri >= 0 ? hHit[(size_t)i].z : 0; }
-            }
-        }
+        if (e == hipSuccess) tryq(trace_device(s, dRays, n, eps, q, hit, ctr, stats, dTri, dTuv, flags));
+        if (e == hipSuccess && outTri) tryq(hipMemcpy(outTri, dTri, 4 * (size_t)n, hipMemcpyDeviceToHost));
+        if (e == hipSuccess && outTuv) tryq(hipMemcpy(outTuv, dTuv, 12 * (size_t)n, hipMemcpyDeviceToHost));
         if (e == hipSuccess && outAny) tryq(hipMemcpy(outAny, flags, (size_t)n, hipMemcpyDeviceToHost));
     }
     (void)hipFree(dRays); (void)hipFree(q.o); (void)hipFree(q.d); (void)hipFree(hit); (void)hipFree(flags); (void)hipFree(ctr); (void)hipFree(stats);
+    (void)hipFree(dTri); (void)hipFree(dTuv);
     if (e != hipSuccess) return fail(MIPT_E_DEVICE, "mipt_trace_rays: %s", hipGetErrorString(e));
+    return MIPT_OK;
+}
+
+// The same queries without a single allocation: rays and results are device arrays of the caller,
+// everything in between lives in this GPU's copy of `scratch`.  Every call on a GPU uses that one
+// array (calls that overlap on one GPU race); what must start at zero - the queue heads and the
+// statistics - is cleared by trace_device, the queue and the hit records are written before they are read.
+int mipt_trace_rays_device(mipt_scene* s, const float* dRays, int64_t n, float eps, int32_t* dTri, float* dTuv, uint8_t* dAny)
+{
+    if (!s || (n > 0 && !dRays)) return fail(MIPT_E_INVALID, "null argument");
+    if (n <= 0) return MIPT_OK;
+    if (n > SCRATCH_RAYS) return fail(MIPT_E_LIMIT, "%lld rays exceed the %d that mipt_trace_rays_device takes per call", (long long)n, (int)SCRATCH_RAYS);
+    int rc = ensure_init();
+    if (rc) return rc;
+    unsigned char* base = g_device < MIPT_MAX_DEVICES ? g_scratchPtr[g_device] : nullptr;
+    if (!base) return fail(MIPT_E_DEVICE, "no scratch memory on device %d", g_device);
+    RayQueue q = { (float4*)(base + SCRATCH_Q_O), (float4*)(base + SCRATCH_Q_D) };
+    hipError_t e = trace_device(s, dRays, n, eps, q, (float4*)(base + SCRATCH_HIT), (int32_t*)(base + SCRATCH_CTR),
+                                (unsigned long long*)(base + SCRATCH_STATS), dTri, dTuv, dAny);
+    if (e != hipSuccess) return fail(MIPT_E_DEVICE, "mipt_trace_rays_device: %s", hipGetErrorString(e));
     return MIPT_OK;
 }
 

@@ -143,3 +143,4 @@ void launch_scatter_accum(const float4* pixAccum, const int32_t* actPix, int32_t
 void launch_finalize(const DevRender& R, const float4* pixState, const float* d_accum, float* d_out, hipStream_t s);
 void launch_set_i32(int32_t* d_ptr, int32_t value, hipStream_t s);
 void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s);
+void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* d_outTuv, hipStream_t s);

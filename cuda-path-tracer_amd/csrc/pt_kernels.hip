@@ -87,6 +87,23 @@ void launch_pack_rays(const float* d_rays6, int64_t n, RayQueue q, hipStream_t s
     hipLaunchKernelGGL(k_pack_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rays6, n, q);
 }
 
+// hit records of caller-supplied rays -> the arrays of mipt_trace_rays: id or -1, (t, ua, va) or zeros
+__global__ void __launch_bounds__(256) k_unpack_hits(const float4* __restrict__ hit, int64_t n, int32_t* outTri, float* outTuv)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 h = hit[i];
+    int32_t tri = __float_as_int(h.w);
+    if (outTri) outTri[i] = tri;
+    if (outTuv) {
+        outTuv[3 * i] = tri >= 0 ? h.x : 0.0f; outTuv[3 * i + 1] = tri >= 0 ? h.y : 0.0f; outTuv[3 * i + 2] = tri >= 0 ? h.z : 0.0f;
+    }
+}
+void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* d_outTuv, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_unpack_hits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hit, n, d_outTri, d_outTuv);
+}
+
 // ---------------------------------------------------------------------------------------
 // Traversal kernels: TraceRays / Intersect of PathTracer.cu:193-288 over a queue of rays.
 //
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     int b = 0;
                     if (lane == 0) b = atomicAdd(head, chunk);
                     b = __builtin_amdgcn_readfirstlane(b);
-                    if (b >= n) queueDry = true;
+                    if ((uint32_t)b >= (uint32_t)n) queueDry = true;      // the head runs past n by up to one chunk per wave and may wrap: compared unsigned
                     else { rangeNext = b; rangeEnd = (b + chunk < n) ? b + chunk : n; }
                 }
             } else {
@@ -206,7 +223,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     int b = 0;
                     if (lane == 0) b = atomicAdd(head, chunk);
                     b = __builtin_amdgcn_readfirstlane(b);
-                    if (b >= n) { queueDry = true; break; }
+                    if ((uint32_t)b >= (uint32_t)n) { queueDry = true; break; }
                     int end = ((b >> MIPT_QBLOCK_SHIFT) << MIPT_QBLOCK_SHIFT) + blockCount[b >> MIPT_QBLOCK_SHIFT];
                     rangeNext = b; rangeEnd = (b + chunk < end) ? b + chunk : end;
                 }

@@ -74,10 +74,12 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)
 
 # every symbol include/mipt.h declares
 E_CANCELLED = -5
+TRACE_DEVICE_MAX_RAYS = 1 << 18
 
 MIPT_SYMBOLS = [
     "mipt_init", "mipt_last_error", "mipt_device_name", "mipt_scene_create", "mipt_scene_destroy",
     "mipt_scene_get_info", "mipt_scene_bvh_sizes", "mipt_scene_bvh_grid", "mipt_scene_download_bvh", "mipt_trace_rays",
+    "mipt_trace_rays_device",
     "mipt_frame_create", "mipt_frame_destroy", "mipt_frame_set_params", "mipt_frame_accumulate",
     "mipt_frame_finalize", "mipt_frame_finalize_partial", "mipt_frame_cancel", "mipt_frame_samples_done",
     "mipt_frame_primary_ids", "mipt_frame_num_pixels", "mipt_render",

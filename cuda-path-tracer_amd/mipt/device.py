@@ -41,6 +41,7 @@ def lib():
         L.mipt_scene_bvh_grid.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mipt_scene_download_bvh.argtypes = [vp, vp, vp, vp, vp]
         L.mipt_trace_rays.argtypes = [vp, vp, i64, f32, vp, vp, vp]
+        L.mipt_trace_rays_device.argtypes = [vp, vp, i64, f32, vp, vp, vp]
         L.mipt_frame_create.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.POINTER(vp)]
         L.mipt_frame_destroy.argtypes = [vp]
         L.mipt_frame_destroy.restype = None
@@ -119,6 +120,11 @@ class Scene:
                                      tri.ctypes.data if closest else None, tuv.ctypes.data if closest else None,
                                      ah.ctypes.data if anyhit else None))
         return tri, tuv, ah
+
+    def trace_rays_device(self, d_rays_ptr, n, eps=1e-20, d_tri_ptr=None, d_tuv_ptr=None, d_any_ptr=None):
+        """mipt_trace_rays_device: rays and results are DEVICE pointers (ints); nothing is allocated."""
+        _check(lib().mipt_trace_rays_device(self._h, C.c_void_p(d_rays_ptr), n, eps, C.c_void_p(d_tri_ptr),
+                                            C.c_void_p(d_tuv_ptr), C.c_void_p(d_any_ptr)))
 
     def render(self, cam, params, want_ids=True, progress=None):
         """mipt_render: whole image into host arrays -> (bgr255 (H,W,3), ids (H,W) or None, Stats)."""

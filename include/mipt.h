@@ -208,6 +208,18 @@ int mipt_scene_download_bvh(const mipt_scene* scene, uint32_t* nodes, float* tri
 int mipt_trace_rays(mipt_scene* scene, const float* rays, int64_t num_rays, float epsilon,
                     int32_t* out_tri, float* out_tuv, uint8_t* out_any);
 
+/* The same two queries for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  This entry point has no
+ * counterpart in the reference.  d_rays (6 floats per ray) and the three outputs are DEVICE arrays
+ * of the caller, each output may be null; the call allocates and frees nothing: its ray queue, hit
+ * records and counters live in a fixed array inside the library's code object (48 bytes per ray,
+ * 12.6 MB, one copy per GPU for the life of the process).  At most MIPT_TRACE_DEVICE_MAX_RAYS rays
+ * per call, MIPT_E_LIMIT beyond.  The call runs on the scene's stream and returns when the results
+ * are complete.  All calls on one GPU share the array: calls that overlap in time race. */
+#define MIPT_TRACE_DEVICE_MAX_RAYS (1 << 18)
+int mipt_trace_rays_device(mipt_scene* scene, const float* d_rays, int64_t num_rays, float epsilon,
+                           int32_t* d_out_tri, float* d_out_tuv, uint8_t* d_out_any);
+
 /* Work buffers for one image size; reused across calls so that a render call
  * allocates nothing. */
 int mipt_frame_create(mipt_scene* scene, const mipt_camera* cam, const mipt_params* params,
