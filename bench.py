@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-image", default="", help="rank 0 saves the final image (float32, H x W x 3, BGR, 0..255) as .npy")
     args = ap.parse_args()
 
     import torch
@@ -200,7 +201,11 @@ def main():
 
     if rank == 0:
         import hashlib
-        image_sha1 = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()   # tile shards add up bit for bit: same hash at any N
+        final = out.cpu().numpy()
+        image_sha1 = hashlib.sha1(final.tobytes()).hexdigest()   # tile shards add up bit for bit: same hash at any N
+        if args.dump_image:
+            import numpy as np
+            np.save(args.dump_image, final.reshape(cam.image_size[1], cam.image_size[0], 3))
         s0 = stats[-1]
         closest_s = tot[3].item() / 1e3                 # rank 0's closest-hit kernel time over the timed steps
         width = int(info.node_width)                    # child boxes tested per node visit

@@ -147,8 +147,9 @@ static bool pack_byte_texels(const float* f, size_t count, uint32_t* dst)
 {
     for (size_t i = 0; i < count; i++) {
         float b = f[3 * i], g = f[3 * i + 1], r = f[3 * i + 2];
+        // (-0.0f is no byte value either: -0/255 and +0/255 differ in their sign bit)
         if (!(b >= 0.0f && b <= 255.0f) || b != (float)(int)b || !(g >= 0.0f && g <= 255.0f) || g != (float)(int)g ||
-            !(r >= 0.0f && r <= 255.0f) || r != (float)(int)r) return false;
+            !(r >= 0.0f && r <= 255.0f) || r != (float)(int)r || signbit(b) || signbit(g) || signbit(r)) return false;
         dst[i] = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | (255u << 24);
     }
     return true;
@@ -510,6 +511,18 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
     int32_t chunk = p->chunk_samples > 0 ? p->chunk_samples : (int32_t)((128ll << 20) / (P > 0 ? P : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > ns) chunk = ns;
+    if (p->chunk_samples <= 0 && f->R.gi) {
+        // the automatic pass also has to fit the memory that is free now (a smaller device, ranks that share
+        // one): 164 bytes per path slot and 180 per pixel, with a tenth of the free memory left alone
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const int64_t perSlot = 16 * 2 * 3 + 16 + 48 + 4, perPixel = 16 * 5 + 64 + 4 + 4 + 16 + 12;
+            int64_t room = (int64_t)(freeB - freeB / 10) - perPixel * P;
+            int64_t fit = room > 0 ? room / (perSlot * P) : 0;
+            if (fit < 1) fit = 1;
+            if (chunk > fit) chunk = (int32_t)fit;
+        }
+    }
     if ((int64_t)chunk * P >= (1ll << 31) - 256) chunk = (int32_t)(((1ll << 31) - 256) / P);
     if (chunk < 1) { delete f; return fail(MIPT_E_LIMIT, "image too large for one pass"); }
     f->chunk = chunk;
@@ -550,7 +563,11 @@ int mipt_frame_set_params(mipt_frame* f, const mipt_camera* cam, const mipt_para
     int32_t passes = (ns + f->chunk - 1) / f->chunk;
     if (CTR_FIXED + CTR_PER_PASS * passes > f->numCounters) return fail(MIPT_E_INVALID, "more samples than the frame was created for");
     if ((p->global_illumination != 0) && f->slotCap == 0) return fail(MIPT_E_INVALID, "frame was created without global illumination");
-    return fill_render(f, cam, p);
+    // values are checked on a copy: a rejected call leaves the frame as it was
+    const DevRender keepR = f->R;
+    int rc = fill_render(f, cam, p);
+    if (rc) f->R = keepR;
+    return rc;
 }
 
 int64_t mipt_frame_num_pixels(const mipt_frame* f) { return f ? f->P : 0; }

@@ -511,11 +511,19 @@ __device__ __forceinline__ float wrap01(float x)
     return x;
 }
 
-__device__ __forceinline__ uint32_t fetch_texel_bgr(const DevScene& S, int fmt, uint64_t off, long idx)
+// The three channel values of a texel as floats, .x = blue.  A byte texel gives (float)byte, which is
+// what both flavours of the reference compute with: the CPU path converts the bytes of a DWORD
+// (CPUPathTracer.cpp:307-309, 331-334), the GPU path reads byte values stored as floats
+// (PathTracer.cu:311-313, 344-346).  A texture of the float pool holds other values than bytes
+// and is used as it is, as PathTracer.cu does.
+__device__ __forceinline__ F3 fetch_texel_bgr(const DevScene& S, int fmt, uint64_t off, long idx)
 {
-    if (fmt == MIPT_TEXFMT_U8) return S.texels[off + (uint64_t)idx];
+    if (fmt == MIPT_TEXFMT_U8) {
+        uint32_t dw = S.texels[off + (uint64_t)idx];
+        return f3((float)(dw & 255u), (float)((dw >> 8) & 255u), (float)((dw >> 16) & 255u));
+    }
     const float* f = S.texelsF + off + (uint64_t)idx * 3;
-    return ((uint32_t)f[0] & 255u) | (((uint32_t)f[1] & 255u) << 8) | (((uint32_t)f[2] & 255u) << 16);
+    return f3(f[0], f[1], f[2]);
 }
 
 // the part of a shading record every hit needs, fetched ahead of its use by bounce shading
@@ -562,8 +570,8 @@ __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender
         long jn = (long)(nmlW * v), hn = (long)(nmlH * u);    // :303-306
         jn = jn < nmlW - 1 ? jn : nmlW - 1;
         hn = hn < nmlH - 1 ? hn : nmlH - 1;
-        uint32_t dw = fetch_texel_bgr(S, nmlFmt, nmlOff, hn * nmlW + jn);
-        float x = (float)(dw & 255u), y = (float)((dw >> 8) & 255u), z = (float)((dw >> 16) & 255u);
+        F3 tx = fetch_texel_bgr(S, nmlFmt, nmlOff, hn * nmlW + jn);
+        float x = tx.x, y = tx.y, z = tx.z;
         nmlMap.x = 2 * z / 255.0f - 1;                        // :315-317
         nmlMap.y = (2 * x / 255.0f - 1);
         nmlMap.z = 2 * y / 255.0f - 1;
@@ -575,8 +583,8 @@ __device__ __forceinline__ Surface surface_at(const DevScene& S, const DevRender
         long j = (long)(texW * v), h = (long)(texH * u);      // :296-299
         j = j < texW - 1 ? j : texW - 1;
         h = h < texH - 1 ? h : texH - 1;
-        uint32_t dw = fetch_texel_bgr(S, texFmt, texOff, h * texW + j);
-        sf.albedo = f3((float)(dw & 255u) / 255.0f, (float)((dw >> 8) & 255u) / 255.0f, (float)((dw >> 16) & 255u) / 255.0f);
+        F3 tx = fetch_texel_bgr(S, texFmt, texOff, h * texW + j);
+        sf.albedo = f3(tx.x / 255.0f, tx.y / 255.0f, tx.z / 255.0f);
     } else {
         float4 dc = a[6];
         sf.albedo = f3(dc.x, dc.y, dc.z);                     // :338

@@ -19,10 +19,10 @@ namespace {
 
 struct Huff {
 	// canonical code tables: for each length the first code, the first value index and the count
-	int32_t mincode[17], maxcode[18], valptr[17];
-	uint8_t vals[256];
-	uint8_t look[512];       // 9-bit prefix -> length (0 = longer than 9 bits)
-	uint8_t lookVal[512];
+	int32_t mincode[17] = {}, maxcode[18] = {}, valptr[17] = {};
+	uint8_t vals[256] = {};
+	uint8_t look[512] = {};  // 9-bit prefix -> length (0 = longer than 9 bits)
+	uint8_t lookVal[512] = {};
 	bool present = false;
 };
 
@@ -146,7 +146,7 @@ inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v))
 
 } // namespace
 
-bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
+static bool LoadJpegUnguarded(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
 {
 	FILE* f = fopen(path, "rb");
 	if (!f) return false;
@@ -203,12 +203,16 @@ bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int3
 			H = u16(seg + 1); W = u16(seg + 3);
 			int nc = buf[seg + 5];
 			if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || seg + 6 + 3 * (size_t)nc > segEnd) return false;
+			if (!comps.empty()) return false;                // a second frame header: not a baseline single-frame file
+			if ((int64_t)W * H > ((int64_t)1 << 28)) return false;
 			comps.assign((size_t)nc, Component());
+			hmax = vmax = 1;
 			for (int i = 0; i < nc; i++) {
 				Component& c = comps[(size_t)i];
 				c.id = buf[seg + 6 + 3 * (size_t)i]; c.h = buf[seg + 7 + 3 * (size_t)i] >> 4; c.v = buf[seg + 7 + 3 * (size_t)i] & 15;
 				c.tq = buf[seg + 8 + 3 * (size_t)i];
 				if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return false;
+				for (int k = 0; k < i; k++) if (comps[(size_t)k].id == c.id) return false;      // every component needs an id of its own
 				if (c.h > hmax) hmax = c.h;
 				if (c.v > vmax) vmax = c.v;
 			}
@@ -221,10 +225,11 @@ bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int3
 			if (comps.empty()) return false;
 			int ns = buf[seg];
 			if (ns != (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > segEnd) return false;   // interleaved single scan only
+			std::vector<bool> assigned(comps.size(), false);
 			for (int i = 0; i < ns; i++) {
 				int cid = buf[seg + 1 + 2 * (size_t)i], tabs = buf[seg + 2 + 2 * (size_t)i];
 				Component* c = nullptr;
-				for (auto& cc : comps) if (cc.id == cid) c = &cc;
+				for (size_t k = 0; k < comps.size(); k++) if (comps[k].id == cid) { c = &comps[k]; if (assigned[k]) return false; assigned[k] = true; }
 				if (!c) return false;
 				c->td = tabs >> 4; c->ta = tabs & 15;
 				if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present || !haveQuant[c->tq]) return false;
@@ -303,6 +308,12 @@ bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int3
 		pos = segEnd;
 	}
 	return false;
+}
+
+bool LoadJpeg(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
+{
+	try { return LoadJpegUnguarded(path, out, width, height); }
+	catch (...) { out.clear(); return false; }      // allocation failure on a hostile size: a decode failure like any other
 }
 
 bool LoadImageFile(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)

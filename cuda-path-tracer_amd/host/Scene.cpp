@@ -502,7 +502,7 @@ bool WritePng(const char* path, const std::vector<uint32_t>& bgra, int32_t width
 // PNG decoding on top of zlib
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
+static bool LoadPngUnguarded(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
 {
 	FILE* f = fopen(path, "rb");
 	if (!f) return false;
@@ -521,6 +521,7 @@ bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32
 		const uint8_t* data = &file[pos + 8];
 		if (pos + 12 + (size_t)len > file.size()) return false;
 		if (!memcmp(type, "IHDR", 4)) {
+			if (len != 13) return false;
 			w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
 		} else if (!memcmp(type, "PLTE", 4)) {
 			for (uint32_t i = 0; i < len / 3 && i < 256; i++) { pal[i][0] = data[3 * i]; pal[i][1] = data[3 * i + 1]; pal[i][2] = data[3 * i + 2]; }
@@ -529,7 +530,7 @@ bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32
 		} else if (!memcmp(type, "IEND", 4)) break;
 		pos += 12 + (size_t)len;
 	}
-	if (!w || !h || interlace) return false;
+	if (!w || !h || interlace || (uint64_t)w * h > ((uint64_t)1 << 28)) return false;     // bounded: no allocation a file can blow up
 	int channels = (ctype == 0) ? 1 : (ctype == 2) ? 3 : (ctype == 3) ? 1 : (ctype == 4) ? 2 : (ctype == 6) ? 4 : 0;
 	if (!channels || !(depth == 8 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
 	size_t bitsPerPixel = (size_t)channels * depth;
@@ -575,6 +576,14 @@ bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32
 		}
 	width = (int32_t)w; height = (int32_t)h;
 	return true;
+}
+
+// A file that cannot be decoded, for whatever reason, is a `false`, never an exception: the callers sit
+// behind a C ABI.
+bool LoadPng(const char* path, std::vector<uint32_t>& out, int32_t& width, int32_t& height)
+{
+	try { return LoadPngUnguarded(path, out, width, height); }
+	catch (...) { out.clear(); return false; }
 }
 
 } // namespace pth

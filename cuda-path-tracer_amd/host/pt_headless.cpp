@@ -1,11 +1,14 @@
 // Headless harness: loads or generates a scene, positions camera and sun the way the
 // reference's GUI does (SideView.cpp:144-164 -> RayTracerView.cpp:783-946), renders through
-// CCUDAPathTracer::CalcRays and writes a PPM.
+// CCUDAPathTracer::CalcRays (--entry gpu, the default: what CalcRayCUDA calls) or through
+// CCPUPathTracer::CalcRays (--entry cpu: what CalcRayCPU calls, RayTracerView.cpp:948-1041) and
+// writes a PPM.
 //
 //   pt_headless --scene cornell|sponza|crytek [--obj file.mesh] [--tris N] [--tex N]
 //               [--samples N] [--gi 0|1] [--textures 0|1] [--normals 0|1] [--div 1|2|4]
-//               [--width W --height H] [--out image.ppm|image.png]
+//               [--width W --height H] [--entry gpu|cpu] [--out image.ppm|image.png]
 #include "../../include/PathTracer.h"
+#include "../../include/CPUPathTracer.h"
 #include "../../include/PTProgress.h"
 #include "../../include/mipt_host.h"
 
@@ -28,7 +31,7 @@ public:
 
 int main(int argc, char** argv)
 {
-	std::string sceneName = "cornell", obj, out = "_ImageHIP.ppm";
+	std::string sceneName = "cornell", obj, out = "_ImageHIP.ppm", entry = "gpu";
 	long width = 1920, height = 1080, samples = 16, div = 1, tris = 0, tex = 1024;
 	bool gi = true, textures = true, normals = false;
 	for (int i = 1; i + 1 < argc; i += 2) {
@@ -39,6 +42,7 @@ int main(int argc, char** argv)
 		else if (k == "--tris") tris = atol(v); else if (k == "--tex") tex = atol(v);
 		else if (k == "--gi") gi = atoi(v) != 0; else if (k == "--textures") textures = atoi(v) != 0;
 		else if (k == "--normals") normals = atoi(v) != 0;
+		else if (k == "--entry") entry = v;
 		else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
 	}
 	int kind = sceneName == "cornell" ? MIPT_SCENE_CORNELL : sceneName == "sponza" ? MIPT_SCENE_SPONZA : MIPT_SCENE_CRYTEK;
@@ -54,6 +58,35 @@ int main(int argc, char** argv)
 	if (samples > 10000) samples = 10000;          // RayTracerView.cpp:785-786
 	mipt_camera cam; float sun[3];
 	if (mipt_host_camera_preset(kind, (int32_t)width, (int32_t)height, (int32_t)div, &cam, sun) != 0) return 1;
+	long W = width / div, H = height / div;
+	std::vector<float3> image((size_t)W * H, float3{ 0, 0, 0 });
+	ConsoleProgress progress;
+	if (entry == "cpu") {
+		// marshal as CRayTracerView::CalcRayCPU does (RayTracerView.cpp:948-981): the scene is the
+		// global mesh list with its DWORD texels, the light a CLight
+		std::vector<DWORD> dwImage((size_t)W * H, 0);
+		DirectX::XMMATRIX toLocalM;
+		memcpy(&toLocalM, cam.to_local, sizeof(toLocalM));
+		CLight sunLight;
+		sunLight.pos = { sun[0], sun[1], sun[2] };
+		CCPUPathTracer::SetScene(d);
+		CCPUPathTracer PT;
+		auto t0 = std::chrono::steady_clock::now();
+		PT.CalcRays(&progress, dwImage.data(), width, height, div, samples, cam.p0, cam.p1, toLocalM, sunLight, gi, textures, normals);
+		double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		fprintf(stderr, "rendered %ldx%ld in %.3f s (CCPUPathTracer entry)\n", W, H, sec);
+		CCPUPathTracer::SetScene(nullptr);
+		// the bytes of the DWORD image, as CalcRayCPU copies them into its CImage (RayTracerView.cpp:1017-1026)
+		for (size_t i = 0; i < dwImage.size(); i++)
+			image[i] = float3{ (float)(dwImage[i] & 255u), (float)((dwImage[i] >> 8) & 255u), (float)((dwImage[i] >> 16) & 255u) };
+		if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0)
+			mipt_host_write_png(out.c_str(), (const float*)image.data(), (int32_t)W, (int32_t)H);
+		else
+			mipt_host_write_ppm(out.c_str(), (const float*)image.data(), (int32_t)W, (int32_t)H);
+		mipt_host_scene_free(hs);
+		return 0;
+	}
+	if (entry != "gpu") { fprintf(stderr, "unknown entry %s (gpu or cpu)\n", entry.c_str()); return 2; }
 	std::vector<CUDAMaterial> mats((size_t)d->num_materials);
 	std::vector<std::vector<float3>> texels((size_t)d->num_materials * 2);
 	auto unpack = [](const void* data, int w, int h, std::vector<float3>& dst) {
@@ -77,11 +110,8 @@ int main(int argc, char** argv)
 		c.bLight = m.is_light != 0;
 		c.pMaterial = m.material >= 0 ? &mats[(size_t)m.material] : nullptr;
 	}
-	long W = width / div, H = height / div;
-	std::vector<float3> image((size_t)W * H, float3{ 0, 0, 0 });
 	float toLocal[4][4];
 	memcpy(toLocal, cam.to_local, sizeof(toLocal));
-	ConsoleProgress progress;
 	auto t0 = std::chrono::steady_clock::now();
 	CCUDAPathTracer::CalcRays(&progress, image.data(), width, height, samples, div, cam.p0, cam.p1, toLocal,
 		float3{ sun[0], sun[1], sun[2] }, float3{ 0, 1, 0 }, 3.0f, gi, textures, normals, meshes.data(), (long)meshes.size(), mats.data(), (long)mats.size());

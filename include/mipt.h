@@ -176,7 +176,15 @@ typedef void (*mipt_progress_fn)(int64_t done, int64_t total, void* user);
 typedef struct mipt_scene mipt_scene;
 typedef struct mipt_frame mipt_frame;
 
-/* Selects the HIP device for this process (PathTracer.cu:577 hard-codes 0). */
+/* Process-wide state, as in the reference (whose render call is not re-entrant either: its device
+ * flags and stack limit are process-global, PathTracer.cu:577,650): the library renders on ONE device
+ * per process, the one of the last mipt_init call (one process per GPU is the intended use), and that
+ * choice is shared by all threads.  A scene owns the HIP stream its frames run on and the spill part
+ * of the traversal stack, which all frames of the scene share: calls on one scene, or on frames of
+ * one scene, must not overlap in time, and a scene must outlive its frames (mipt_scene_destroy with a
+ * frame still alive leaves that frame unusable).  Different scenes may be used from different threads.
+ *
+ * Selects the HIP device for this process (PathTracer.cu:577 hard-codes 0). */
 int mipt_init(int32_t device);
 const char* mipt_last_error(void);
 int mipt_device_name(char* buf, int32_t buflen);

@@ -221,8 +221,12 @@ typedef struct pto_mesh {
 } pto_mesh;
 
 typedef struct pto_mat {
-    uint32_t* tex; int32_t w, h;   /* DWORD texels, byte0 = blue (framework.h:130-132) */
-    uint32_t* nml; int32_t nw, nh;
+    /* A texture is held in the layout it was given in: DWORD texels, byte0 = blue (CMesh::m_pTexData,
+       framework.h:130-132, what the CPU path reads) or three floats per texel, .x = blue
+       (CUDAMaterial::pTexData, PathTracer.h:21, what the GPU path reads).  Exactly one of the two
+       pointers of a texture is set. */
+    uint32_t* tex; float* texf; int32_t w, h;
+    uint32_t* nml; float* nmlf; int32_t nw, nh;
     float diffuse[3];
 } pto_mat;
 
@@ -307,19 +311,21 @@ static void node_free(pto_node* n)
     free(n->tris); free(n->ids);
 }
 
-static uint32_t* texels_to_dword(const void* data, int32_t w, int32_t h, int32_t fmt)
+static void copy_texels(const void* data, int32_t w, int32_t h, int32_t fmt, uint32_t** dw, float** fl)
 {
-    if (!data || w <= 0 || h <= 0 || fmt == MIPT_TEX_NONE) return NULL;
+    *dw = NULL; *fl = NULL;
+    if (!data || w <= 0 || h <= 0 || fmt == MIPT_TEX_NONE) return;
     size_t n = (size_t)w * (size_t)h;
-    uint32_t* out = (uint32_t*)malloc(n * 4);
-    if (fmt == MIPT_TEX_BGRA8) { memcpy(out, data, n * 4); return out; }
-    const float* f = (const float*)data;      /* byte values as floats, RayTracerView.cpp:824-826 */
-    for (size_t i = 0; i < n; i++) {
-        uint32_t b = (uint32_t)f[3 * i + 0] & 255u, g = (uint32_t)f[3 * i + 1] & 255u,
-                 r = (uint32_t)f[3 * i + 2] & 255u;
-        out[i] = b | (g << 8) | (r << 16) | (255u << 24);
-    }
-    return out;
+    if (fmt == MIPT_TEX_BGRA8) { *dw = (uint32_t*)malloc(n * 4); memcpy(*dw, data, n * 4); }
+    else { *fl = (float*)malloc(n * 12); memcpy(*fl, data, n * 12); }   /* RayTracerView.cpp:819-842 */
+}
+
+/* The three channel values of a texel as floats, .x = blue.  From a DWORD texel they are the bytes
+   (CPUPathTracer.cpp:307-309, 331-334); a float texel is taken as it is (PathTracer.cu:311-313, 344-346). */
+static inline f3 texel_bgr(const uint32_t* dw, const float* fl, long idx)
+{
+    if (dw) { uint32_t t = dw[idx]; return f3_make((float)(t & 255u), (float)((t >> 8) & 255u), (float)((t >> 16) & 255u)); }
+    return f3_make(fl[3 * idx], fl[3 * idx + 1], fl[3 * idx + 2]);
 }
 
 pto_scene* pto_scene_create(const mipt_scene_desc* desc)
@@ -330,10 +336,10 @@ pto_scene* pto_scene_create(const mipt_scene_desc* desc)
     for (int32_t i = 0; i < s->nmats; i++) {
         const mipt_material* m = &desc->materials[i];
         pto_mat* o = &s->mats[i];
-        o->tex = texels_to_dword(m->tex_data, m->tex_width, m->tex_height, m->tex_format);
-        if (o->tex) { o->w = m->tex_width; o->h = m->tex_height; }
-        o->nml = texels_to_dword(m->nml_data, m->nml_width, m->nml_height, m->nml_format);
-        if (o->nml) { o->nw = m->nml_width; o->nh = m->nml_height; }
+        copy_texels(m->tex_data, m->tex_width, m->tex_height, m->tex_format, &o->tex, &o->texf);
+        if (o->tex || o->texf) { o->w = m->tex_width; o->h = m->tex_height; }
+        copy_texels(m->nml_data, m->nml_width, m->nml_height, m->nml_format, &o->nml, &o->nmlf);
+        if (o->nml || o->nmlf) { o->nw = m->nml_width; o->nh = m->nml_height; }
         memcpy(o->diffuse, m->diffuse, sizeof(o->diffuse));
     }
     s->nmeshes = desc->num_meshes;
@@ -359,7 +365,7 @@ void pto_scene_destroy(pto_scene* s)
 {
     if (!s) return;
     for (int32_t i = 0; i < s->nmeshes; i++) node_free(&s->meshes[i].root);
-    for (int32_t i = 0; i < s->nmats; i++) { free(s->mats[i].tex); free(s->mats[i].nml); }
+    for (int32_t i = 0; i < s->nmats; i++) { free(s->mats[i].tex); free(s->mats[i].nml); free(s->mats[i].texf); free(s->mats[i].nmlf); }
     free(s->meshes); free(s->mats); free(s);
 }
 
@@ -379,6 +385,27 @@ void pto_scene_octree_info(const pto_scene* s, int64_t* nodes, int32_t* max_dept
     if (nodes) *nodes = nn;
     if (max_depth) *max_depth = md;
     if (leaf_triangles) *leaf_triangles = lf;
+}
+
+static void node_mark_leaves(const pto_node* n, uint8_t* seen)
+{
+    if (n->child) { for (int h = 0; h < 8; h++) node_mark_leaves(&n->child[h], seen); return; }
+    for (int32_t k = 0; k < n->ntris; k++) if (n->ids[k] >= 0) seen[n->ids[k]] = 1;
+}
+void pto_scene_octree_reachable(const pto_scene* s, int32_t mesh, int64_t* total, int64_t* reachable, uint8_t* mask)
+{
+    uint8_t* seen = (uint8_t*)calloc((size_t)(s->ntris > 0 ? s->ntris : 1), 1);
+    int64_t tot = 0, got = 0;
+    for (int32_t i = 0; i < s->nmeshes; i++) {
+        if (s->meshes[i].is_light || (mesh >= 0 && i != mesh)) continue;
+        tot += s->meshes[i].root.ntris;
+        node_mark_leaves(&s->meshes[i].root, seen);
+    }
+    for (int64_t k = 0; k < s->ntris; k++) got += seen[k];
+    if (mask) memcpy(mask, seen, (size_t)s->ntris);
+    free(seen);
+    if (total) *total = tot;
+    if (reachable) *reachable = got;
 }
 
 /* ------------------------------------------------------------------ */
@@ -522,8 +549,7 @@ static int trace_full(rctx* R, f3 o, f3 d, int hit_only, f3* hitpoint, f3* nmlMe
     const pto_mat* mat = (m->material >= 0 && m->material < R->s->nmats) ? &R->s->mats[m->material] : NULL;
     long nTexWidth = mat ? mat->w : 0, nTexHeight = mat ? mat->h : 0;
     long nNmlWidth = mat ? mat->nw : 0, nNmlHeight = mat ? mat->nh : 0;
-    const uint32_t* pTexData = mat ? mat->tex : NULL;
-    const uint32_t* pNmlData = mat ? mat->nml : NULL;
+    const int hasTex = mat && (mat->tex || mat->texf), hasNml = mat && (mat->nml || mat->nmlf);
     /* wrap loops :292-295; values the loop cannot bring into range (NaN, |x| >= 2^24) are
        set to 0 so that the loops terminate */
     if (!(fabsf(u) < 16777216.0f)) u = 0;
@@ -536,13 +562,13 @@ static int trace_full(rctx* R, f3 o, f3 d, int hit_only, f3* hitpoint, f3* nmlMe
     long h = (long)(nTexHeight * u);
     j = (j < nTexWidth - 1) ? j : nTexWidth - 1;
     h = (h < nTexHeight - 1) ? h : nTexHeight - 1;
-    if (pNmlData) {                                                  /* :301-318 */
+    if (hasNml) {                                                    /* :301-318 */
         long jn = (long)(nNmlWidth * v);
         long hn = (long)(nNmlHeight * u);
         jn = (jn < nNmlWidth - 1) ? jn : nNmlWidth - 1;
         hn = (hn < nNmlHeight - 1) ? hn : nNmlHeight - 1;
-        uint32_t dw = pNmlData[hn * nNmlWidth + jn];
-        float x = (float)(dw & 255u), y = (float)((dw >> 8) & 255u), z = (float)((dw >> 16) & 255u);
+        f3 t = texel_bgr(mat->nml, mat->nmlf, hn * nNmlWidth + jn);
+        float x = t.x, y = t.y, z = t.z;
         nmlMap->x = 2 * z / 255.0f - 1;
         nmlMap->y = (2 * x / 255.0f - 1);
         nmlMap->z = 2 * y / 255.0f - 1;
@@ -550,11 +576,11 @@ static int trace_full(rctx* R, f3 o, f3 d, int hit_only, f3* hitpoint, f3* nmlMe
     }
     if (!R->p->use_textures) {                                       /* :320-326 */
         *rgb = f3_make(0.5f, 0.5f, 0.5f);
-    } else if (pTexData && nTexWidth > 0) {                          /* :330-335 */
-        uint32_t dw = pTexData[h * nTexWidth + j];
-        rgb->x = (float)(dw & 255u) / 255.0f;
-        rgb->y = (float)((dw >> 8) & 255u) / 255.0f;
-        rgb->z = (float)((dw >> 16) & 255u) / 255.0f;
+    } else if (hasTex && nTexWidth > 0) {                            /* :330-335 */
+        f3 t = texel_bgr(mat->tex, mat->texf, h * nTexWidth + j);
+        rgb->x = t.x / 255.0f;
+        rgb->y = t.y / 255.0f;
+        rgb->z = t.z / 255.0f;
     } else {
         *rgb = mat ? f3_ld(mat->diffuse) : f3_make(0, 0, 0);         /* :338 */
     }

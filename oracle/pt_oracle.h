@@ -77,6 +77,16 @@ void pto_scene_destroy(pto_scene* s);
 int64_t pto_scene_num_triangles(const pto_scene* s);
 /* number of octree nodes and maximum subdivision depth over all meshes (Mesh.cpp:44-56) */
 void pto_scene_octree_info(const pto_scene* s, int64_t* nodes, int32_t* max_depth, int64_t* leaf_triangles);
+/* How much of a mesh its octree can still find.  CMesh::ComputeSubmeshes gives a triangle to an
+ * octant only if one of its corners lies inside the octant's box (CMesh::AddTriangle,
+ * Mesh.cpp:168-186), with the boxes computed from centre +- extent in fp32 (Mesh.cpp:95-141).  After
+ * a child box has been re-fitted (RecomputeBB, Mesh.cpp:153-156) the faces of its own octants can
+ * land one ulp inside the re-fitted box, and a triangle whose three corners lie on that face of the
+ * box is then in no octant: the search (CMesh::Intersect, CPUPathTracer.cpp:195-249) only tests
+ * leaf triangles, so it can never hit it.  mesh = -1 sums over all non-light meshes.
+ * *total = triangles of the mesh(es); *reachable = distinct triangles present in at least one leaf;
+ * mask (optional, one byte per global triangle id) = 1 where the triangle is in a leaf. */
+void pto_scene_octree_reachable(const pto_scene* s, int32_t mesh, int64_t* total, int64_t* reachable, uint8_t* mask);
 
 /* CCPUPathTracer::Trace search part, CPUPathTracer.cpp:251-285 */
 int pto_trace(const pto_scene* s, const float o[3], const float d[3], float eps, int accel,

@@ -54,6 +54,7 @@ def lib():
         L.pto_scene_num_triangles.restype = C.c_int64
         L.pto_scene_num_triangles.argtypes = [C.c_void_p]
         L.pto_scene_octree_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.pto_scene_octree_reachable.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
         L.pto_trace.argtypes = [C.c_void_p, F3, F3, C.c_float, C.c_int, C.POINTER(Hit)]
         L.pto_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int]
@@ -104,6 +105,18 @@ class OracleScene:
         n, d, l = C.c_int64(), C.c_int32(), C.c_int64()
         lib().pto_scene_octree_info(self._h, C.byref(n), C.byref(d), C.byref(l))
         return n.value, d.value, l.value
+
+    def octree_reachable(self, mesh=-1):
+        """(triangles of the mesh, or of all non-light meshes for -1; of these, present in at least one octree leaf)"""
+        t, r = C.c_int64(), C.c_int64()
+        lib().pto_scene_octree_reachable(self._h, mesh, C.byref(t), C.byref(r), None)
+        return t.value, r.value
+
+    def octree_reachable_mask(self, mesh=-1):
+        """one byte per global triangle id: 1 where the triangle is in at least one leaf of the mesh(es)"""
+        mask = np.zeros(self.num_triangles, dtype=np.uint8)
+        lib().pto_scene_octree_reachable(self._h, mesh, None, None, mask.ctypes.data)
+        return mask
 
     def trace(self, o, d, eps=1e-20, accel=ACCEL_BRUTE):
         h = Hit()

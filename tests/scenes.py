@@ -59,3 +59,39 @@ def scene_from_triangles(tris):
     desc.num_meshes = 1
     desc.num_materials = 0
     return desc, (verts, mesh)
+
+
+def with_float_textures(scene, offset_materials=(), offset=0.5):
+    """The scene's descriptor with every texture and normal map given as three floats per texel
+    (MIPT_TEX_F32X3), the layout the reference's GPU path is handed (CUDAMaterial::pTexData,
+    PathTracer.h:21, filled at RayTracerView.cpp:819-842: the bytes of the DWORD texel as floats,
+    .x = blue).  Textures of the materials in offset_materials get `offset` added to every value, so
+    that they hold numbers no byte can hold.  Returns (pointer to desc, keepalive)."""
+    import ctypes as C
+    src = scene.desc.contents
+    mats = (abi.Material * src.num_materials)()
+    keep = [mats]
+
+    def to_float(ptr, w, h, shift):
+        dw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(w * h,))
+        fl = np.stack([dw & 255, (dw >> 8) & 255, (dw >> 16) & 255], axis=1).astype(np.float32)
+        if shift:
+            fl += np.float32(shift)
+        keep.append(fl)
+        return fl.ctypes.data
+
+    for i in range(src.num_materials):
+        m = src.materials[i]
+        o = mats[i]
+        o.diffuse = m.diffuse
+        shift = offset if i in offset_materials else 0.0
+        if m.tex_data and m.tex_format == abi.MIPT_TEX_BGRA8:
+            o.tex_data, o.tex_width, o.tex_height, o.tex_format = to_float(m.tex_data, m.tex_width, m.tex_height, shift), m.tex_width, m.tex_height, abi.MIPT_TEX_F32X3
+        if m.nml_data and m.nml_format == abi.MIPT_TEX_BGRA8:
+            o.nml_data, o.nml_width, o.nml_height, o.nml_format = to_float(m.nml_data, m.nml_width, m.nml_height, shift), m.nml_width, m.nml_height, abi.MIPT_TEX_F32X3
+    desc = abi.SceneDesc()
+    desc.vertices, desc.num_triangles = src.vertices, src.num_triangles
+    desc.meshes, desc.num_meshes = src.meshes, src.num_meshes
+    desc.materials, desc.num_materials = C.cast(mats, C.POINTER(abi.Material)), src.num_materials
+    keep.append(scene)
+    return C.pointer(desc), keep

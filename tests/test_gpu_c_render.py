@@ -61,6 +61,33 @@ def test_atrium_direct_textures_and_normal_maps(gpu, atrium_small, atrium_small_
     assert img.max() > 10          # something is lit
 
 
+@pytest.mark.parametrize("use_normals,nnm", [(0, 0), (1, 0), (1, 1)])
+def test_float3_texels_as_the_reference_uploads_them(gpu, atrium_small, atrium_small_oracle, use_normals, nnm):
+    """The texel layout CCUDAPathTracer::CalcRays really receives: three floats per texel
+    (RayTracerView.cpp:819-842).  Byte-valued float textures are repacked to four bytes per texel by
+    the library and must give the image of the DWORD textures bit for bit; textures with other values
+    (two materials here hold x.5 everywhere) stay float and are used as PathTracer.cu:311-313,344-346
+    uses them, value / 255, which the oracle restates for float texels."""
+    cam, sun = scenes.crytek_camera(div=4)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, use_textures=1, use_normals=use_normals,
+                              normalize_normal_map=nnm)
+    # byte values only: identical to the DWORD-texel render
+    fdesc, keep = scenes.with_float_textures(atrium_small)
+    img, ids, _ = gpu.Scene(fdesc).render(cam, prm)
+    oimg, _, otri, _ = atrium_small_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids, otri) and np.array_equal(img, oimg)
+    # non-byte values in the two largest materials (meshes are ordered by triangle count)
+    shifted = tuple(sorted({m for _, _, m, _ in atrium_small.meshes()[:2] if m >= 0}))
+    assert shifted
+    fdesc2, keep2 = scenes.with_float_textures(atrium_small, offset_materials=shifted)
+    osc2 = ob.OracleScene(fdesc2)
+    img2, ids2, _ = gpu.Scene(fdesc2).render(cam, prm)
+    oimg2, _, otri2, _ = osc2.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(ids2, otri2)
+    assert np.array_equal(img2.view(np.uint32), oimg2.view(np.uint32))
+    assert not np.array_equal(img2, img)            # the half levels are visible in the image
+
+
 def gi_compare(img, oimg, n_samples):
     diff = img.astype(np.float64) - oimg.astype(np.float64)
     rmse = float(np.sqrt((diff ** 2).mean()))

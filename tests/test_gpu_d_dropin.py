@@ -35,18 +35,69 @@ def test_headless_calcrays_cornell(gpu, tmp_path, cornell_oracle):
     cam, sun = scenes.cornell_camera(div=4)
     prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=8)
     oimg, dword, _, _ = cornell_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
-    # the PPM holds the truncated bytes in RGB order; the oracle's DWORD is b | g<<8 | r<<16 (CPUPathTracer.cpp:509)
-    want = np.stack([(dword >> 16) & 255, (dword >> 8) & 255, dword & 255], axis=2).astype(np.uint8)
-    assert np.array_equal(img, want)
+    assert np.array_equal(img, dword_to_rgb(dword))
 
 
-def test_headless_calcrays_atrium_gi(gpu, tmp_path):
-    out = tmp_path / "atrium.ppm"
+def dword_to_rgb(dword):
+    """The PPM holds the truncated bytes in RGB order; a DWORD of the CPU entry is b | g << 8 | r << 16 (CPUPathTracer.cpp:509)."""
+    return np.stack([(dword >> 16) & 255, (dword >> 8) & 255, dword & 255], axis=2).astype(np.uint8)
+
+
+def test_headless_calcrays_textured_atrium_against_oracle(gpu, tmp_path):
+    """CCUDAPathTracer::CalcRays with textures: the harness hands over float3 texels exactly as
+    RayTracerView.cpp:813-863 does, the library repacks them; the image must be the oracle's.  Direct
+    light (no random numbers): every byte equal.  GI: same random stream, sin/cos from two math
+    libraries, so a few paths bifurcate: mean within three standard errors, most bytes equal."""
+    scene = host.HostScene.atrium(abi.SCENE_SPONZA, 20000, 64, 1)
+    osc = ob.OracleScene(scene.desc)
+    cam, sun = host.camera_preset(abi.SCENE_SPONZA, 1920, 1080, 8)
+    for normals in (0, 1):
+        out = tmp_path / f"atrium_direct_{normals}.ppm"
+        p = subprocess.run([HEADLESS, "--scene", "sponza", "--tris", "20000", "--tex", "64", "--div", "8", "--gi", "0",
+                            "--normals", str(normals), "--out", str(out)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        prm = host.default_params(sun_pos=sun, global_illumination=0, use_textures=1, use_normals=normals)
+        _, dword, otri, _ = osc.render(cam, prm, accel=ob.ACCEL_BRUTE)
+        img = read_ppm(out)
+        assert img.shape == (135, 240, 3) and (otri >= 0).mean() > 0.9 and img.mean() > 5
+        assert np.array_equal(img, dword_to_rgb(dword)), f"normals={normals}"
+    out = tmp_path / "atrium_gi.ppm"
     p = subprocess.run([HEADLESS, "--scene", "sponza", "--tris", "20000", "--tex", "64", "--div", "8", "--samples", "4",
                         "--out", str(out)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
-    img = read_ppm(out)
-    assert img.shape == (135, 240, 3) and img.mean() > 5
+    img = read_ppm(out).astype(np.float64)
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=4, use_textures=1)
+    _, dword, _, _ = osc.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    want = dword_to_rgb(dword).astype(np.float64)
+    sigma = want.std() / np.sqrt(want.size)
+    print(f"CalcRays atrium GI N=4: identical bytes {(img == want).mean():.4f}, |dmean| {abs(img.mean() - want.mean()):.4g}, sigma {sigma:.4g}")
+    assert abs(img.mean() - want.mean()) <= 3 * sigma and (img == want).mean() > 0.9
+
+
+def test_headless_cpu_entry_against_oracle(gpu, tmp_path, cornell_oracle):
+    """CCPUPathTracer::CalcRays (include/CPUPathTracer.h, the surface of CPUPathTracer.h:17-18): DWORD image,
+    nDiv before nNumSamples, a CLight, the scene set beforehand.  Its DWORD image must be the oracle's."""
+    out = tmp_path / "cornell_cpu_entry.ppm"
+    p = subprocess.run([HEADLESS, "--entry", "cpu", "--scene", "cornell", "--obj", CORNELL, "--div", "4", "--gi", "0", "--samples", "8",
+                        "--out", str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "progress 129600 / 129600" in p.stderr and "CCPUPathTracer entry" in p.stderr
+    cam, sun = scenes.cornell_camera(div=4)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=8)
+    _, dword, _, _ = cornell_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(read_ppm(out), dword_to_rgb(dword))
+    # textured, with normal maps, through the same entry: DWORD texels go in as they are
+    scene = host.HostScene.atrium(abi.SCENE_CRYTEK, 20000, 64, 1)
+    osc = ob.OracleScene(scene.desc)
+    out = tmp_path / "atrium_cpu_entry.ppm"
+    p = subprocess.run([HEADLESS, "--entry", "cpu", "--scene", "crytek", "--tris", "20000", "--tex", "64", "--div", "8", "--gi", "0",
+                        "--normals", "1", "--out", str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    cam, sun = host.camera_preset(abi.SCENE_CRYTEK, 1920, 1080, 8)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, use_textures=1, use_normals=1)
+    _, dword, otri, _ = osc.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert (otri >= 0).mean() > 0.9
+    assert np.array_equal(read_ppm(out), dword_to_rgb(dword))
 
 
 def test_default_sponza_standin_direct_and_gi(gpu):
@@ -60,12 +111,17 @@ def test_default_sponza_standin_direct_and_gi(gpu):
     oimg, _, otri, _ = osc.render(cam, prm, accel=ob.ACCEL_BRUTE)
     assert np.array_equal(ids, otri) and np.array_equal(img, oimg)
     assert (ids >= 0).mean() > 0.9
-    # The reference's own octree search is NOT the brute-force result on this scene: its box test
-    # (xnacollision.cpp:1228-1297) rejects rays whose hit lies on a face of a mesh's bounding box - here the
-    # outer walls, which define that box - so about a tenth of the primary rays lose their nearest hit.
+    # The reference's own octree search is NOT the brute-force result on this scene, because its octree does not
+    # hold every triangle: CMesh::ComputeSubmeshes (Mesh.cpp:88-166) files a triangle under the octants that
+    # contain one of its corners, and for corners that lie on a face of a re-fitted box the fp32 point test
+    # (AddTriangle, Mesh.cpp:168-186) fails by one ulp, so triangles lying in such a face - flat walls and floors -
+    # end up in no leaf and can never be hit (tests/test_oracle_kat.py pins the arithmetic and the counts).
+    # The GPU path searches all triangles; its image is deliberately not the octree's on such a scene.
+    total, reachable = osc.octree_reachable()
+    assert (total, reachable) == (66012, 61852)
     qimg, _, qtri, _ = osc.render(cam, prm, accel=ob.ACCEL_OCTREE)
-    print(f"octree search agrees with brute force on {(qtri == otri).mean():.4f} of the pixels")
-    assert (qtri == otri).mean() > 0.85
+    print(f"octree holds {reachable} of {total} triangles; its search agrees with brute force on {(qtri == otri).mean():.4f} of the pixels")
+    assert 0.85 < (qtri == otri).mean() < 0.95
     cam8, _ = host.camera_preset(abi.SCENE_SPONZA, 1920, 1080, 8)
     prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=4)
     img, ids, st = sc.render(cam8, prm)
@@ -76,10 +132,14 @@ def test_default_sponza_standin_direct_and_gi(gpu):
     print(f"sponza stand-in GI N=4: rmse={np.sqrt(((img - oimg) ** 2).mean()):.4g} identical={(img == oimg).mean():.4f}")
 
 
-def test_ten_million_triangles(gpu):
-    """Config 5 of the baseline: ~38 flattened instances of the 262k-triangle scene.  The BVH must
-    build, and random rays must agree with brute force bit for bit."""
-    base = host.HostScene.atrium(abi.SCENE_CRYTEK, 262000, 0, 1)
+def test_config5_ten_million_triangles_gi512(gpu):
+    """Config 5 of the baseline: ~38 flattened instances of the 262k-triangle scene (~10 M triangles), GI
+    with 512 first-bounce samples, client 3840x2160 (rendered at div 8 here).  The BVH must build, random
+    rays must agree with brute force bit for bit, and the render is checked through properties that do not
+    need the oracle's whole image: 32 passes of 16 samples give the image of the automatic pass size,
+    eight tile shards add up to it bit for bit, every value is a colour, and one image row of ids and
+    direct light equals the oracle's brute-force search over all 10 M triangles."""
+    base = host.HostScene.atrium(abi.SCENE_CRYTEK, 262000, 64, 1)
     big = base.instanced(38, 4000.0)
     assert big.num_triangles > 9_900_000
     sc = gpu.Scene(big.desc)
@@ -92,3 +152,34 @@ def test_ten_million_triangles(gpu):
     otri, otuv, oany = osc.trace_rays(rays, accel=ob.ACCEL_BRUTE)
     assert np.array_equal(tri, otri) and np.array_equal(anyhit, oany)
     assert np.array_equal(tuv.view(np.uint32), otuv.view(np.uint32))
+
+    cam, sun = host.camera_preset(abi.SCENE_CRYTEK, 3840, 2160, 8)
+    W, H = cam.image_size
+    npx = W * H
+    gi = dict(sun_pos=sun, global_illumination=1, num_samples=512, use_textures=1)
+    ref, ids, st = sc.render(cam, host.default_params(**gi))
+    assert st.samples_done == 512 and st.closest_rays + st.shadow_rays + st.shadow_rays_culled > 2.5e8
+    assert np.isfinite(ref).all() and ref.min() >= 0 and ref.max() <= 255 and (ids >= 0).mean() > 0.9
+    img, _, st16 = sc.render(cam, host.default_params(chunk_samples=16, **gi))
+    assert st16.chunk_samples == 16 and st16.closest_launches >= 1 + 3 * 32          # 32 passes of three bounce levels
+    assert np.array_equal(img, ref)
+    total = np.zeros(npx * 3, dtype=np.float32)
+    first = None
+    for r in range(8):
+        fr = gpu.Frame(sc, cam, host.default_params(shard_rank=r, shard_count=8, chunk_samples=64, **gi))
+        acc = gpu.DeviceBuffer(npx * 12)
+        fr.accumulate(acc.ptr)
+        total += acc.to_host()
+        if first is None:
+            first = fr
+    acc, out = gpu.DeviceBuffer(npx * 12), gpu.DeviceBuffer(npx * 12)
+    acc.from_host(total)
+    first.finalize(acc.ptr, out.ptr)
+    assert np.array_equal(out.to_host().reshape(H, W, 3), ref)
+    # one row against the brute-force search (direct light: no random numbers involved)
+    direct = host.default_params(sun_pos=sun, global_illumination=0, use_textures=1)
+    dimg, dids, _ = sc.render(cam, direct)
+    row = H // 2
+    oimg, _, orow, _ = osc.render(cam, direct, accel=ob.ACCEL_BRUTE, row_step=H, row_phase=row)
+    assert np.array_equal(dids[row], orow[row]) and np.array_equal(ids[row], orow[row])
+    assert np.array_equal(dimg[row].view(np.uint32), oimg[row].view(np.uint32))

@@ -252,3 +252,50 @@ def test_png_writer_and_image_compare(tmp_path):
     assert differ.returncode == 1 and "differ" in differ.stdout
     host.write_png(str(tmp_path / "small.png"), img[:5], w, 5)
     assert subprocess.run([tool, str(png), str(tmp_path / "small.png")], capture_output=True).returncode == 1
+
+
+def test_decoders_refuse_malformed_headers(tmp_path):
+    """Files that lie about themselves are refused, not decoded with missing tables or sizes: a JPEG whose
+    frame header names one component id twice (the scan then leaves a component without Huffman tables), a
+    JPEG with two frame headers, a PNG whose IHDR chunk is shorter than its 13 bytes, a PNG with absurd
+    dimensions."""
+    import struct
+    import zlib
+    PIL = pytest.importorskip("PIL.Image")
+    img = (np.arange(16 * 16 * 3, dtype=np.uint32).reshape(16, 16, 3) * 7 % 256).astype(np.uint8)
+    good = str(tmp_path / "good.jpg")
+    PIL.fromarray(img, "RGB").save(good, "JPEG", quality=90, subsampling=0)
+    assert host.load_image(good).shape == (16, 16)
+    data = bytearray(open(good, "rb").read())
+    sof = data.index(b"\xff\xc0")
+    assert data[sof + 9] == 3                            # three components; ids at +10, +13, +16
+    dup = bytearray(data)
+    dup[sof + 13] = dup[sof + 10]                        # second component takes the id of the first
+    bad = tmp_path / "dup_ids.jpg"
+    bad.write_bytes(bytes(dup))
+    with pytest.raises(IOError):
+        host.load_image(str(bad))
+    seg_len = struct.unpack(">H", data[sof + 2:sof + 4])[0]
+    twice = data[:sof + 2 + seg_len] + data[sof:sof + 2 + seg_len] + data[sof + 2 + seg_len:]
+    bad = tmp_path / "two_sof.jpg"
+    bad.write_bytes(bytes(twice))
+    with pytest.raises(IOError):
+        host.load_image(str(bad))
+
+    def chunk(kind, payload):
+        return struct.pack(">I", len(payload)) + kind + payload + struct.pack(">I", zlib.crc32(kind + payload))
+
+    raw = b"".join(b"\x00" + bytes(row) for row in img.reshape(16, 48))
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = struct.pack(">IIBBBBB", 16, 16, 8, 2, 0, 0, 0)
+    ok = tmp_path / "ok.png"
+    ok.write_bytes(sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert host.load_png(str(ok)).shape == (16, 16)
+    short = tmp_path / "short_ihdr.png"
+    short.write_bytes(sig + chunk(b"IHDR", ihdr[:12]) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    with pytest.raises(IOError):
+        host.load_png(str(short))
+    huge = tmp_path / "huge.png"
+    huge.write_bytes(sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 30, 1 << 30, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    with pytest.raises(IOError):
+        host.load_png(str(huge))

@@ -189,6 +189,48 @@ def test_octree_structure_and_agreement_on_atrium(atrium_small, atrium_small_ora
     assert (g0[0] == g1[0]).mean() > 0.999 and (g0[2] == g1[2]).mean() > 0.999
 
 
+def test_octree_drops_triangles_that_lie_on_a_refitted_box_face():
+    """The reference's octree loses triangles (it is the reference's behaviour, restated faithfully).
+    CMesh::ComputeSubmeshes gives a triangle to an octant if one of its corners passes the point test
+    |p - centre| <= extent (XNA::IntersectPointAxisAlignedBox, xnacollision.cpp:964-972, called from
+    AddTriangle, Mesh.cpp:168-186) with the octant's centre = parent centre +- extent/2 and extent =
+    parent extent/2 in fp32 (Mesh.cpp:95-132).  Once the parent box has been re-fitted to its triangles
+    (RecomputeBB, Mesh.cpp:153-156) its faces are no round numbers any more, and for a corner ON such a
+    face the difference p - centre can round to one ulp more than the octant's extent: a triangle with
+    all three corners in that face is then in no octant.  The search only tests leaf triangles
+    (CMesh::Intersect, CPUPathTracer.cpp:195-249), so it can never hit such a triangle."""
+    f = np.float32
+    # one box of the 66 k-triangle stand-in (mesh 6, depth 1): re-fitted to z in [-4.0833335, -3.4166667]
+    lo, hi = f(-4.0833335), f(-3.4166667)
+    c, e = f((lo + hi) / f(2)), f((hi - lo) / f(2))            # set_box_from_minmax / RecomputeBB
+    assert (c, e) == (f(-3.75), f(0.33333337))
+    oc, oe = f(c - f(e / f(2))), f(e / f(2))                   # the lower octants, Mesh.cpp:95-132
+    assert f(oc - oe) == lo                                    # their lower face IS the box face, and yet
+    assert abs(f(lo - oc)) == f(0.16666675) and oe == f(0.16666669) and not abs(f(lo - oc)) <= oe
+    assert not ob.lib().pto_point_in_aabb(ob.f3(0, 0, lo), ob.f3(0, 0, oc), ob.f3(1, 1, oe))
+    scene = host.HostScene.atrium(abi.SCENE_SPONZA, 66000, 0, 1)
+    osc = ob.OracleScene(scene.desc)
+    assert osc.octree_reachable() == (66012, 61852)
+    assert osc.octree_reachable(6) == (3564, 1278)            # the worst mesh: 64 % of its triangles are in no leaf
+    # a ray aimed at the middle of a lost triangle: the brute-force search finds it, the octree walk cannot
+    mask = osc.octree_reachable_mask()
+    lost = np.flatnonzero(mask == 0)
+    first, count, _, _ = scene.meshes()[6]
+    lost6 = lost[(lost >= first) & (lost < first + count)]
+    assert len(lost6) == 3564 - 1278
+    tri = scene.vertices()[lost6[:64], :, :3].astype(np.float64)
+    centre = tri.mean(axis=1)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rays = np.concatenate([centre + 0.05 * nrm, -nrm], axis=1).astype(np.float32)
+    tb, _, _ = osc.trace_rays(rays, accel=ob.ACCEL_BRUTE)
+    to, _, _ = osc.trace_rays(rays, accel=ob.ACCEL_OCTREE)
+    assert np.array_equal(tb, lost6[:64]) and not np.isin(to, lost6).any()
+    # small scenes lose nothing: no mesh of the Cornell box is subdivided, and the 10 k stand-in keeps all
+    small_scene = host.HostScene.atrium(abi.SCENE_CRYTEK, 10000, 0, 1)
+    assert ob.OracleScene(small_scene.desc).octree_reachable() == (10008, 10008)
+
+
 def test_direct_image_properties(cornell, cornell_oracle):
     cam, sun = scenes.cornell_camera(div=8)
     prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=8)
