@@ -244,6 +244,7 @@ def main():
                 "closest_rays_per_s": tot[8].item() / closest_s if closest_s > 0 else 0.0,
                 "algorithmic_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
                 "hbm_frac": (bytes_ / closest_s / 1e9) / HBM_PEAK_GBS if closest_s > 0 else 0.0,
+                "closest_ms_per_step": [round(s.closest_ms, 3) for s in stats], "shadow_ms_per_step": [round(s.shadow_ms, 3) for s in stats],
                 "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed),
                                       "shading": tot[9].item() / (1e3 * elapsed)},
             },

@@ -627,6 +627,16 @@ static int collapse_to_wide(BvhResult* out, const std::vector<int32_t>& levelEnd
     return rc;
 }
 
+// Child codes of the finished tree: one index space, node slots first, leaf slots behind them.
+__global__ void __launch_bounds__(256) k_unify_codes(uint4* wide, int64_t numSlots, uint32_t leafBase)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numSlots) return;
+    uint4 c = wide[i * 4 + 3];
+    auto fix = [&](uint32_t x) { return (x != MIPT_NO_NODE && (x & MIPT_LEAF_BIT)) ? leafBase + (x & ~MIPT_LEAF_BIT) : x; };
+    wide[i * 4 + 3] = make_uint4(fix(c.x), fix(c.y), fix(c.z), fix(c.w));
+}
+
 void mipt_free_bvh(BvhResult* r)
 {
     if (!r) return;
@@ -749,6 +759,16 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         float hostMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (getenv("MIPT_BUILD_VERBOSE")) fprintf(stderr, "bvh build: %d triangles, device %.2f ms, collapse to wide nodes %.2f ms\n", n, (float)out->buildMs, hostMs);
         out->buildMs += hostMs;
+    }
+    if (out->rootCode & MIPT_LEAF_BIT) {
+        // the whole scene is one leaf: no node slots at all, the root is leaf slot 0
+        (void)hipFree(out->nodes); out->nodes = nullptr;
+        out->numNodeSlots = 0;
+        out->rootCode = 0;
+    } else {
+        hipLaunchKernelGGL(k_unify_codes, dim3((unsigned)((out->numNodeSlots + 255) / 256)), dim3(256), 0, stream, out->nodes, out->numNodeSlots, (uint32_t)out->numNodeSlots);
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipGetLastError());
     }
 done:
     if (primMin) (void)hipFree(primMin);

@@ -317,7 +317,15 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
         int v = atoi(e);
         if (v >= 1 && v < D.stackLds) D.stackLds = v;
     }
-    D.numTris = (int32_t)n; D.numMats = s->numMats;
+    D.numTris = (int32_t)n; D.numMats = s->numMats; D.numNodeSlots = s->bvh.numNodeSlots;
+    D.leafBase = (uint32_t)s->bvh.numNodeSlots;
+    {
+        uint64_t codes = (uint64_t)s->bvh.numNodeSlots + (uint64_t)s->bvh.numLeafSlots;      // child codes are 0 .. codes - 1
+        if (codes >= (1ull << 30)) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too large"); }
+        uint32_t m = 1;
+        while (m < codes) m <<= 1;
+        D.slotMask = m - 1;
+    }
     if (D.stackDepth > D.stackLds) {
         // one slice per wave that can be resident: 32 per compute unit
         size_t bytes = (size_t)(D.stackDepth - D.stackLds) * 64 * 4 * (size_t)g_numCUs * 32;
@@ -687,6 +695,10 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
 #ifdef MIPT_TRACE_PROFILE
         fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu\n",
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6]);
+#endif
+#ifdef MIPT_TRACE_HIST
+        fprintf(stderr, "trace histogram (closest): nodeVisits %llu | of these at node slot < 256: %llu  < 512: %llu  < 1024: %llu  < 2048: %llu  < 4096: %llu | with stack depth >= 6: %llu  >= 9: %llu  >= 12: %llu\n",
+                h[ST_CLOSEST_NODES], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7]);
 #endif
         stats->node_visits = h[ST_CLOSEST_NODES] + h[ST_SHADOW_NODES];
         stats->triangle_tests = h[ST_CLOSEST_TRIS] + h[ST_SHADOW_TRIS];

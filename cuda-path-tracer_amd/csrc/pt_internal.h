@@ -13,10 +13,11 @@
 // box test only has to be generous, never tight.  One word per child and axis, min | max << 16:
 //   words 3k .. 3k+2 = x, y, z of child k;  words 12 .. 15 = child codes
 // An unused child has min > max (word 0x0000FFFF) and code MIPT_NO_NODE.
-// A child code with bit 31 set is a leaf: bits 0..30 = first leaf slot.  A leaf slot is one
+// Child codes are indices into one space that holds the node slots first and the leaf slots after
+// them: a code below DevScene::leafBase (= the number of node slots) is an inner node, a code c at
+// or above it is a leaf whose first triangle is leaf slot c - leafBase.  A leaf slot is one
 // record of MIPT_TRI_F4 float4 in BVH order (triangles of one leaf are consecutive), so that the
-// three loads of a lane fall into one cache line: the traversal is limited by the number of
-// distinct lines its lanes touch, not by arithmetic.
+// three loads of a lane fall into one cache line.
 //   tris[s * MIPT_TRI_F4 + 0] = (v0.xyz, bits global triangle id)
 //   tris[s * MIPT_TRI_F4 + 1] = (v1 - v0, bits 1 if last triangle of its leaf else 0)
 //   tris[s * MIPT_TRI_F4 + 2] = (v2 - v0, 0)
@@ -24,11 +25,11 @@
 #define MIPT_TRI_F4 4      // 64-byte records: a record never straddles a 128-byte line
 #endif
 #define MIPT_NODE_WIDTH 4
-#define MIPT_STACK_LDS_MAX 22   // stack entries per lane kept in LDS (5.5 KiB per wave: 28 waves per compute unit)
+#define MIPT_STACK_LDS_MAX 16   // stack entries (4 bytes) per lane kept in LDS (4 KiB per wave); deeper entries, which one node visit in ten thousand needs, go to the spill slice
 #define MIPT_SHADE_F4 8
 // A queue in blocks: entries [b << MIPT_QBLOCK_SHIFT, (b << MIPT_QBLOCK_SHIFT) + blockCount[b]) of every block b are valid
 #define MIPT_QBLOCK_SHIFT 10
-#define MIPT_LEAF_BIT 0x80000000u
+#define MIPT_LEAF_BIT 0x80000000u   // marks leaves in the binary tree the builder works on; the finished tree uses leafBase
 #define MIPT_NO_NODE  0xFFFFFFFFu
 
 #define MIPT_TEXFMT_NONE 0
@@ -54,11 +55,14 @@ struct DevScene {
     float              qmin[3];    // origin and cell size of the 16-bit grid the node boxes live on
     float              qcell[3];
     uint32_t           rootCode;   // MIPT_NO_NODE for an empty scene
+    uint32_t           leafBase;   // child codes from here on are leaves (= number of node slots)
+    uint32_t           slotMask;   // 2^b - 1 with the smallest b that holds every child code; the bits above it carry the sort key in a stack entry
     int32_t            stackDepth; // entries of the per-lane traversal stack the tree can need
     int32_t            stackLds;   // of these, entries kept in LDS; the rest live in stackSpill
     uint32_t*          stackSpill; // (stackDepth - stackLds) * 64 entries per resident wave, or null
     int32_t            numTris;
     int32_t            numMats;
+    int64_t            numNodeSlots;
 };
 
 // render constants handed to the shading kernels by value

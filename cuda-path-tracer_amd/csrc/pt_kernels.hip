@@ -134,11 +134,13 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
+#define TRACE_WAVES 12            // waves per workgroup
+#define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
 #define TRACE_TRI_VOTE 16
 #define TRACE_NODE_DROP 40
 #define TRACE_TRI_STAY 2      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
-#define LANE_IDLE     0x7FFFFFFFu   // no ray; inner node indices are below LANE_FINISHED, leaf codes have bit 31 set
+#define LANE_IDLE     0x7FFFFFFFu   // no ray; every child code is below LANE_FINISHED
 
 __device__ __forceinline__ void stack_store(uint32_t* lds, uint32_t* spill, int ldsCap, int idx, uint32_t v)
 {
@@ -150,46 +152,69 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32
     if (idx < ldsCap) return lds[idx * WAVE];
     return spill ? spill[(size_t)(idx - ldsCap) * WAVE] : LANE_FINISHED;
 }
-// compare-exchange of (key, code) pairs: afterwards ka <= kb.  Keys are bit patterns of
-// non-negative floats (or their distance from the largest finite one), +inf for a miss: they order
-// like unsigned integers.
-#define KEY_MISS 0x7f800000u
-__device__ __forceinline__ void order_pair(uint32_t& ka, uint32_t& ca, uint32_t& kb, uint32_t& cb)
-{
-    bool swap = kb < ka;
-    uint32_t kmin = ka < kb ? ka : kb, kmax = ka < kb ? kb : ka;
-    uint32_t cmin = swap ? cb : ca, cmax = swap ? ca : cb;
-    ka = kmin; kb = kmax; ca = cmin; cb = cmax;
-}
-// Sort key of a child: closest hit descends nearest first (the entry distance), any hit descends
-// first into the child the ray spends the longest way in (measured: it meets an occluder sooner
-// than nearest-first, any-hit kernel -10 %).  KEY_MISS where the ray misses the box.
+// A child that the ray has to visit travels as ONE word, in the sort and on the stack: the child
+// code in the low bits (DevScene::slotMask) and, above them, the high bits of its sort key.  Closest
+// hit descends nearest first, the key is the entry distance of the box; any hit descends first into
+// the child the ray spends the longest way in (measured: it meets an occluder sooner than
+// nearest-first, any-hit kernel -10 %), the key is the largest finite float minus that length.
+// Keys are bit patterns of non-negative floats: they order like unsigned integers, so the four
+// entries of a node are sorted with integer min/max alone, and cutting the low bits of a key off
+// rounds it down.  That keeps the second use of the key safe: when a closest-hit entry is popped and
+// its (rounded down) entry distance lies beyond the best hit found meanwhile, the child is dropped
+// without being fetched.  A child that was missed is ENTRY_MISS, above every entry of a hit.
+#define ENTRY_MISS 0x7fffffffu
 template <int MODE>
-__device__ __forceinline__ uint32_t box_key(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, int& hits)
+__device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t slotMask, int& hits)
 {
     float t0, t1;
     bool h = box_test(r, wx, wy, wz, tcull, t0, t1);
     hits += h;
-    if (MODE != 0) return h ? 0x7f7fffffu - __float_as_uint(t1 - t0) : KEY_MISS;
-    return h ? __float_as_uint(t0) : KEY_MISS;
+    uint32_t key = (MODE != 0) ? 0x7f7fffffu - __float_as_uint(t1 - t0) : __float_as_uint(t0);
+    uint32_t e = (code & slotMask) | (key & ~slotMask);
+    return h ? e : ENTRY_MISS;
+}
+// compare-exchange: afterwards a <= b
+__device__ __forceinline__ void order_pair(uint32_t& a, uint32_t& b)
+{
+    uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
 }
 
 template <int MODE, bool BLOCKS>
-__global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
-                                               const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
-                                               float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                               float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagInHit)
+__global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
+                                                const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
+                                                float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
+                                                float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagInHit, int cacheSlots)
 {
-    extern __shared__ uint32_t smem[];
-    const int lane = threadIdx.x;
-    uint32_t* stack = smem + lane;
-    const int n = *d_count;
-    const uint4* __restrict__ nodes = S.nodes;
+    // LDS of the workgroup: the first cacheSlots node slots of the tree (its top levels, where more than
+    // half of all node visits go), then one stack area per wave.  The waves of a workgroup share the
+    // node copy and nothing else: after the copy is made they never meet again.
+    extern __shared__ uint4 smem4[];
+    const int lane = threadIdx.x & (WAVE - 1), waveInGroup = threadIdx.x / WAVE;
+    constexpr bool CULL = (MODE == 0);      // closest hit: entries whose box lies beyond the best hit are dropped when popped
     const int ldsCap = S.stackLds;
-    uint32_t* spill = S.stackSpill ? S.stackSpill + (size_t)blockIdx.x * (size_t)(S.stackDepth - S.stackLds) * WAVE + lane : nullptr;
+    const uint4* __restrict__ nodes = S.nodes;
+    const uint32_t leafBase = S.leafBase, slotMask = S.slotMask;
+    for (int i = threadIdx.x; i < cacheSlots * 4; i += blockDim.x) smem4[i] = nodes[i];
+    __syncthreads();
+    uint32_t* stack = (uint32_t*)(smem4 + (size_t)cacheSlots * 4) + (size_t)waveInGroup * ldsCap * WAVE + lane;
+    const int n = *d_count;
+    // per-wave slice of the spill area
+    const size_t waveId = (size_t)blockIdx.x * (blockDim.x / WAVE) + waveInGroup;
+    uint32_t* spill = S.stackSpill ? S.stackSpill + waveId * (size_t)(S.stackDepth - ldsCap) * WAVE + lane : nullptr;
+    // a lane is at an inner node (cur < leafBase), at a triangle of a leaf (leafBase <= cur < LANE_FINISHED), finished or idle
+    auto at_node = [&](uint32_t c) { return c < leafBase; };
+    auto at_leaf = [&](uint32_t c) { return c - leafBase < LANE_FINISHED - leafBase; };
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD)
+    float ablF = 0.0f, ablG = 0.0f; uint32_t ablU = 0;
+#endif
 #ifdef MIPT_TRACE_PROFILE
     uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0;
+#endif
+#ifdef MIPT_TRACE_HIST
+    // where the node visits go (by node slot: low slots are the top of the tree) and how deep the stack gets
+    uint32_t hSlot[5] = { 0, 0, 0, 0, 0 }, hDeep[3] = { 0, 0, 0 };
 #endif
 
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
@@ -200,7 +225,36 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     BoxRay br = {};
     float tcull = FLT_MAX;
+    uint32_t cullEntry = ENTRY_MISS;        // entries above this one lie beyond the best hit: bits of tcull with the code bits all set
     Hit best; best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
+    // result of a finished ray
+    auto write_result = [&]() {
+        bool found = best.tri >= 0;
+        if (MODE == 0) {
+            // the shading kernels do not use the distance: with tagInHit the ray's slot id travels in its place
+            hit[rayIdx] = make_float4(tagInHit ? __int_as_float(tag0) : best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
+        } else if (MODE == 1) {
+            if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
+                if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
+                else pathState[(size_t)(tag1 - 1) * slotsPerLevel + tag0].x = 0.0f;
+            }
+        } else {
+            flags[rayIdx] = found ? 1 : 0;
+        }
+    };
+    // next entry of the stack that is still worth a visit, or LANE_FINISHED
+    auto pop = [&]() -> uint32_t {
+        if (CULL) {
+            while (sp > 0) {
+                sp--;
+                uint32_t e = stack_load(stack, spill, ldsCap, sp);
+                if (e <= cullEntry) return e & slotMask;
+            }
+            return LANE_FINISHED;
+        }
+        if (sp > 0) { sp--; return stack_load(stack, spill, ldsCap, sp) & slotMask; }
+        return LANE_FINISHED;
+    };
 
     for (;;) {
 #ifdef MIPT_TRACE_PROFILE
@@ -240,7 +294,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     o = f3(o4.x, o4.y, o4.z); d = f3(d4.x, d4.y, d4.z);
                     tag0 = __float_as_int(o4.w); tag1 = __float_as_int(d4.w);
                     br = make_box_ray(S, o, d);
-                    tcull = FLT_MAX;
+                    tcull = FLT_MAX; cullEntry = ENTRY_MISS;
                     best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
                     sp = 0;
                     rayCount++;
@@ -250,7 +304,7 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                 rangeNext += (want < avail) ? want : avail;
             }
         }
-        unsigned long long triMask = __ballot((int32_t)cur < 0), nodeMask = __ballot(cur < LANE_FINISHED);
+        unsigned long long triMask = __ballot(at_leaf(cur)), nodeMask = __ballot(at_node(cur));
         if ((triMask | nodeMask) == 0 && __ballot(cur == LANE_FINISHED) == 0) {
             if (queueDry && rangeNext >= rangeEnd) break;
             continue;
@@ -266,19 +320,47 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_PROFILE
                 pNodeIters++;
 #endif
-                if (cur < LANE_FINISHED) {
-                    const uint4* nd = nodes + (size_t)cur * 4;
-                    uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+                if (at_node(cur)) {
+                    uint4 w0, w1, w2, w3;
+                    if (cur < (uint32_t)cacheSlots) {       // the top of the tree is read from the workgroup's copy in LDS
+                        const uint4* nd = smem4 + cur * 4;
+                        w0 = nd[0]; w1 = nd[1]; w2 = nd[2]; w3 = nd[3];
+                        // keeps the two kinds of load apart: merged into one flat load they would all go through the
+                        // vector memory pipeline, which is what the copy in LDS is there to relieve
+                        asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x));
+                    } else {
+                        const uint4* nd = nodes + (size_t)cur * 4;
+                        w0 = nd[0]; w1 = nd[1]; w2 = nd[2]; w3 = nd[3];
+                        asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x));
+                    }
                     nodeCount++;
-                    // sort key per child, KEY_MISS where the ray misses the child's box
+#ifdef MIPT_ABLATE_VALU
+                    // what one more vector instruction per node step costs: MIPT_ABLATE_VALU of them, half v_max_f32, half v_cvt_f32_u32, outside the data flow
+                    for (int k = 0; k < MIPT_ABLATE_VALU; k += 2) {
+                        asm volatile("v_max_f32 %0, %0, %1" : "+v"(ablF) : "v"(tcull));
+                        asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(w3.x));
+                    }
+#endif
+#ifdef MIPT_ABLATE_LOAD
+                    // what one more 16-byte load of the node's own cache line costs (lanes that read the node from memory only)
+                    if (cur >= (uint32_t)cacheSlots) {
+                        const uint4* alias = nodes;
+                        asm volatile("" : "+s"(alias));
+                        for (int k = 0; k < MIPT_ABLATE_LOAD; k++) ablU ^= alias[(size_t)cur * 4 + (k & 3)].y;
+                    }
+#endif
+#ifdef MIPT_TRACE_HIST
+                    hSlot[0] += cur < 256u; hSlot[1] += cur < 512u; hSlot[2] += cur < 1024u; hSlot[3] += cur < 2048u; hSlot[4] += cur < 4096u;
+                    hDeep[0] += sp >= 6; hDeep[1] += sp >= 9; hDeep[2] += sp >= 12;
+#endif
+                    // one entry per child, ENTRY_MISS where the ray misses the child's box
                     int hits = 0;
-                    uint32_t k0 = box_key<MODE>(br, w0.x, w0.y, w0.z, tcull, hits), k1 = box_key<MODE>(br, w0.w, w1.x, w1.y, tcull, hits);
-                    uint32_t k2 = box_key<MODE>(br, w1.z, w1.w, w2.x, tcull, hits), k3 = box_key<MODE>(br, w2.y, w2.z, w2.w, tcull, hits);
-                    uint32_t c0 = w3.x, c1 = w3.y, c2 = w3.z, c3 = w3.w;
-                    // five compare-exchanges sort the four (key, child) pairs
-                    order_pair(k0, c0, k1, c1); order_pair(k2, c2, k3, c3);
-                    order_pair(k0, c0, k2, c2); order_pair(k1, c1, k3, c3);
-                    order_pair(k1, c1, k2, c2);
+                    uint32_t e0 = box_entry<MODE>(br, w0.x, w0.y, w0.z, tcull, w3.x, slotMask, hits), e1 = box_entry<MODE>(br, w0.w, w1.x, w1.y, tcull, w3.y, slotMask, hits);
+                    uint32_t e2 = box_entry<MODE>(br, w1.z, w1.w, w2.x, tcull, w3.z, slotMask, hits), e3 = box_entry<MODE>(br, w2.y, w2.z, w2.w, tcull, w3.w, slotMask, hits);
+                    // five compare-exchanges sort the four entries
+                    order_pair(e0, e1); order_pair(e2, e3);
+                    order_pair(e0, e2); order_pair(e1, e3);
+                    order_pair(e1, e2);
                     // The children that were hit are the first `hits`; the nearest is visited now, the
                     // others go on the stack, farthest deepest: child j lands at sp + hits - 1 - j.  For a
                     // child that was missed that offset is negative; taken modulo 4 it points above the
@@ -286,31 +368,29 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                     // unconditional (the stack has three spare entries).
                     int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
                     if (__builtin_expect(__ballot(sp + 3 >= ldsCap) == 0, 1)) {
-                        stack[p1 * WAVE] = c1; stack[p2 * WAVE] = c2; stack[p3 * WAVE] = c3;
+                        stack[p1 * WAVE] = e1; stack[p2 * WAVE] = e2; stack[p3 * WAVE] = e3;
                     } else {
-                        stack_store(stack, spill, ldsCap, p1, c1); stack_store(stack, spill, ldsCap, p2, c2); stack_store(stack, spill, ldsCap, p3, c3);
+                        stack_store(stack, spill, ldsCap, p1, e1); stack_store(stack, spill, ldsCap, p2, e2); stack_store(stack, spill, ldsCap, p3, e3);
                     }
                     if (hits > 0) {
                         sp += hits - 1;
-                        cur = c0;
-                    } else if (sp > 0) {
-                        sp--; cur = stack_load(stack, spill, ldsCap, sp);
+                        cur = e0 & slotMask;
                     } else {
-                        cur = LANE_FINISHED;
+                        cur = pop();
                     }
                 }
-            } while (__popcll(__ballot(cur < LANE_FINISHED)) > stay);
+            } while (__popcll(__ballot(at_node(cur))) > stay);
         };
         // ---- triangle steps: the exact triangle test on one triangle of the lane's leaf
         auto triPhase = [&]() {
-#ifdef MIPT_TRACE_PROFILE
-            pTriIters++;
-#endif
             // further triangle steps follow at once while enough of the lanes that entered are still at a leaf
             const int triKeep = (__popcll(triMask) * triStay) >> 3;
             do {
-                if ((int32_t)cur < 0) {
-                    uint32_t slot = cur & ~MIPT_LEAF_BIT;
+#ifdef MIPT_TRACE_PROFILE
+                pTriIters++;
+#endif
+                if (at_leaf(cur)) {
+                    uint32_t slot = cur - leafBase;
                     const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
                     float4 a = tr[0], b = tr[1], c = tr[2];
                     triCount++;
@@ -323,48 +403,46 @@ __global__ void __launch_bounds__(WAVE) k_trace(DevScene S, RayQueue q, const in
                         } else if (t < best.t || (t == best.t && id < best.tri)) {
                             best.t = t; best.u = u; best.v = v; best.tri = id;
                             tcull = t * 1.0000153f;       // boxes are culled a little beyond the best hit
+                            cullEntry = __float_as_uint(tcull) | slotMask;
                         }
                     }
                     bool last = __float_as_uint(b.w) != 0 || slot + 1 >= (uint32_t)S.numTris;
                     if (occluded) { cur = LANE_FINISHED; }
                     else if (!last) { cur = cur + 1; }
-                    else if (sp > 0) { sp--; cur = stack_load(stack, spill, ldsCap, sp); }
-                    else { cur = LANE_FINISHED; }
+                    else { cur = pop(); }
                 }
-            } while (triStay > 0 && __popcll(__ballot((int32_t)cur < 0)) > triKeep);
+            } while (triStay > 0 && __popcll(__ballot(at_leaf(cur))) > triKeep);
         };
         // the triangle phase follows the node phase in the same round
         if (nodeMask != 0 && __popcll(triMask) < triVote) {
             nodePhase();
-            triMask = __ballot((int32_t)cur < 0); nodeMask = __ballot(cur < LANE_FINISHED);
+            triMask = __ballot(at_leaf(cur)); nodeMask = __ballot(at_node(cur));
         }
         if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) triPhase();
 #ifdef MIPT_TRACE_PROFILE
         { unsigned long long fm = __ballot(cur == LANE_FINISHED); if (fm) { pFinish++; pFinishLanes += __popcll(fm); } }
 #endif
         if (cur == LANE_FINISHED) {
-            bool found = best.tri >= 0;
-            if (MODE == 0) {
-                // the shading kernels do not use the distance: with tagInHit the ray's slot id travels in its place
-                hit[rayIdx] = make_float4(tagInHit ? __int_as_float(tag0) : best.t, best.u, best.v, __int_as_float(found ? best.tri : -1));
-            } else if (MODE == 1) {
-                if (found) {       // occluded: no direct light at this hit (PathTracer.cu:421-428)
-                    if (tag1 == 0) pixState0[(size_t)tag0 * 4].x = 0.0f;
-                    else pathState[(size_t)(tag1 - 1) * slotsPerLevel + tag0].x = 0.0f;
-                }
-            } else {
-                flags[rayIdx] = found ? 1 : 0;
-            }
+            write_result();
             cur = LANE_IDLE;
         }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
+#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD)
+    if (ablF + ablG == 12345.678f && ablU == 0x12345u) stats[ST_PROF] = 1;      // keeps the extra work alive
+#endif
 #ifdef MIPT_TRACE_PROFILE
     if (lane == 0 && MODE == 0) {
         atomicAdd(&stats[ST_PROF + 0], (unsigned long long)pOuter); atomicAdd(&stats[ST_PROF + 1], (unsigned long long)pNodeIters);
         atomicAdd(&stats[ST_PROF + 2], (unsigned long long)pTriIters); atomicAdd(&stats[ST_PROF + 3], (unsigned long long)pNodePhases);
         atomicAdd(&stats[ST_PROF + 4], (unsigned long long)pRefills); atomicAdd(&stats[ST_PROF + 5], (unsigned long long)pFinish);
         atomicAdd(&stats[ST_PROF + 6], (unsigned long long)pFinishLanes);
+    }
+#endif
+#ifdef MIPT_TRACE_HIST
+    if (MODE == 0) {
+        for (int k = 0; k < 5; k++) { unsigned long long v = wave_sum_u32(hSlot[k]); if (lane == 0) atomicAdd(&stats[ST_PROF + k], v); }
+        for (int k = 0; k < 3; k++) { unsigned long long v = wave_sum_u32(hDeep[k]); if (lane == 0) atomicAdd(&stats[ST_PROF + 5 + k], v); }
     }
 #endif
     if (lane == 0 && rs) {
@@ -402,52 +480,69 @@ static int trace_chunk()
     return v;
 }
 
-static size_t trace_smem(const DevScene& S)
+// Shape of a traversal launch: waves per workgroup, node slots copied to LDS, LDS bytes per workgroup,
+// workgroups in the grid.  The grid is sized to the machine (the waves are persistent): as many
+// workgroups per compute unit as its 160 KiB of LDS and its 32 wave slots admit.
+struct TraceShape { int waves; int cacheSlots; size_t smem; int grid; };
+
+static int env_int(const char* name, int dflt)
 {
-    static int extra = -1;      // MIPT_TRACE_LDS_EXTRA: additional bytes per wave, to study occupancy
-    if (extra < 0) { const char* e = getenv("MIPT_TRACE_LDS_EXTRA"); extra = e ? atoi(e) : 0; }
-    return (size_t)S.stackLds * WAVE * sizeof(uint32_t) + (size_t)extra;
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
-static int trace_grid(int32_t maxCount, int numCUs, size_t smemBytes)
+static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount, int numCUs, int64_t numNodeSlots)
 {
-    // waves that can be resident: limited by LDS (160 KiB per CU) and by 32 waves per CU
-    int perCU = smemBytes ? (int)((160 * 1024) / smemBytes) : 32;
-    if (perCU > 32) perCU = 32;
+    static int wavesEnv = -1, cacheEnv = -1, extra = -1;
+    if (wavesEnv < 0) {
+        wavesEnv = env_int("MIPT_TRACE_WAVES", TRACE_WAVES); if (wavesEnv < 1) wavesEnv = 1; if (wavesEnv > 16) wavesEnv = 16;
+        cacheEnv = env_int("MIPT_TRACE_CACHE", TRACE_CACHE_SLOTS); if (cacheEnv < 0) cacheEnv = 0;
+        extra = env_int("MIPT_TRACE_LDS_EXTRA", 0);      // additional bytes per workgroup, to study occupancy
+    }
+    TraceShape t;
+    t.waves = wavesEnv;
+    t.cacheSlots = (int)(numNodeSlots < cacheEnv ? numNodeSlots : cacheEnv);
+    const size_t perWave = (size_t)S.stackLds * WAVE * sizeof(uint32_t);
+    t.smem = (size_t)t.cacheSlots * 64 + perWave * (size_t)t.waves + (size_t)extra;
+    while (t.smem > 160 * 1024 && t.cacheSlots > 0) { t.cacheSlots /= 2; t.smem = (size_t)t.cacheSlots * 64 + perWave * (size_t)t.waves + (size_t)extra; }
+    int perCU = t.smem ? (int)((160 * 1024) / t.smem) : 32;
+    if (perCU * t.waves > 32) perCU = 32 / t.waves;
     if (perCU < 1) perCU = 1;
     long long resident = (long long)numCUs * perCU;
-    long long needed = ((long long)maxCount + trace_chunk() - 1) / trace_chunk();
+    long long neededWaves = ((long long)maxCount + trace_chunk() - 1) / trace_chunk();
+    long long needed = (neededWaves + t.waves - 1) / t.waves;
     long long g = needed < resident ? needed : resident;
-    return (int)(g < 1 ? 1 : g);
+    t.grid = (int)(g < 1 ? 1 : g);
+    return t;
 }
 
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit)
 {
-    size_t smem = trace_smem(S);
-    hipLaunchKernelGGL((k_trace<0, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0);
+    TraceShape t = trace_shape(S, true, maxCount, numCUs, S.numNodeSlots);
+    hipLaunchKernelGGL((k_trace<0, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
+                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
                    unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
-    size_t smem = trace_smem(S);
+    TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
     int chunk = trace_chunk();
     if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK;   // must divide a block
     if (d_blockCount)
-        hipLaunchKernelGGL((k_trace<1, true>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
-                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
+        hipLaunchKernelGGL((k_trace<1, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head,
+                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
     else
-        hipLaunchKernelGGL((k_trace<1, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, d_blockCount, d_head,
-                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0);
+        hipLaunchKernelGGL((k_trace<1, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head,
+                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
-    size_t smem = trace_smem(S);
-    hipLaunchKernelGGL((k_trace<2, false>), dim3(trace_grid(maxCount, numCUs, smem)), dim3(WAVE), smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0);
+    TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
+    hipLaunchKernelGGL((k_trace<2, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ while front.size:
     c = codes[front]
     valid = c != 0xFFFFFFFF
     hist += np.bincount(valid.sum(axis=1), minlength=5)
-    leaf = valid & ((c & 0x80000000) != 0)
+    leaf = valid & (c >= nodes.shape[0])      # codes from the number of node slots on are leaf slots
     leaves += int(leaf.sum())
     front = c[valid & ~leaf].astype(np.int64)
     depth += 1

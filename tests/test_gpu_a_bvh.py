@@ -8,8 +8,6 @@ from mipt import abi, host
 
 pytestmark = pytest.mark.gpu
 
-LEAF = 0x80000000
-
 
 def validate_bvh(scene_host, dev_scene):
     info = dev_scene.info()
@@ -40,12 +38,14 @@ def validate_bvh(scene_host, dev_scene):
     if root == 0xFFFFFFFF:
         assert n == 0
         return info
+    # child codes index one space: node slots first, leaf slots behind them
+    leaf_base = nodes.shape[0]
     stack = [(int(root), 0, None, None)]
     while stack:
         code, depth, lo, hi = stack.pop()
         max_depth = max(max_depth, depth)
-        if code & LEAF:
-            s = code & 0x7FFFFFFF
+        if code >= leaf_base:
+            s = code - leaf_base
             e = s
             while last[e] == 0:
                 e += 1
