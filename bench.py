@@ -31,7 +31,7 @@ WORKLOADS = {
     "crytek38x_gi512_2160p": ("crytek", 262000, 1024, 512, 1, 3840, 2160, 1, 38),
 }
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet, packed fp32 FMA
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # plain v_fma_f32: 256 CUs x 4 SIMDs x 32 lanes per cycle x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 FLOP_PER_TRI_TEST = 51              # full Moeller-Trumbore from three vertices
 FLOP_PER_BOX_TEST = 22
@@ -180,6 +180,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # one more frame, untimed, with the closest-hit kernel counting the child boxes that exist in the nodes it
+    # visits (the frames are deterministic: the count holds for the timed ones): a node visit tests 2..4 boxes
+    params.count_box_tests = 1
+    frame.set_params(cam, params)
+    counted = frame.accumulate(accum.data_ptr())
+    boxes_per_visit = counted.closest_box_tests / max(counted.closest_node_visits, 1)
+
     tot = torch.tensor([
         float(sum(s.closest_rays + s.shadow_rays for s in stats)),
         float(sum(s.closest_triangle_tests for s in stats)), float(sum(s.closest_node_visits for s in stats)),
@@ -208,11 +215,13 @@ def main():
             np.save(args.dump_image, final.reshape(cam.image_size[1], cam.image_size[0], 3))
         s0 = stats[-1]
         closest_s = tot[3].item() / 1e3                 # rank 0's closest-hit kernel time over the timed steps
-        width = int(info.node_width)                    # child boxes tested per node visit
-        flops = FLOP_PER_TRI_TEST * tot[1].item() + FLOP_PER_BOX_TEST * width * tot[2].item()
+        width = int(info.node_width)                    # child slots per node
+        # algorithmic work of the closest-hit kernel: box tests against children that exist, triangle tests
+        flops = FLOP_PER_TRI_TEST * tot[1].item() + FLOP_PER_BOX_TEST * boxes_per_visit * tot[2].item()
         bytes_ = BYTES_PER_TRI_TEST * tot[1].item() + BYTES_PER_NODE_CHILD * width * tot[2].item()
         achieved_tf = flops / closest_s / 1e12 if closest_s > 0 else 0.0
         launches = max(tot[4].item(), 1.0)
+        traffic = measured_traffic(args.workload)
         result = {
             "metric": "Mrays/s (1 & 8 GPU) + render time, Crytek Sponza GI 128 spp 1080p",
             "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -235,15 +244,19 @@ def main():
             "roofline": {
                 "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
                 "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(args.workload),
+                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes per launch, fabric side of L2 (profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": bytes_ / launches,
                 "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
                 "triangle_tests_per_s": tot[1].item() / closest_s if closest_s > 0 else 0.0,
                 "node_visits_per_s": tot[2].item() / closest_s if closest_s > 0 else 0.0,
                 "closest_rays_per_s": tot[8].item() / closest_s if closest_s > 0 else 0.0,
-                "algorithmic_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
-                "hbm_frac": (bytes_ / closest_s / 1e9) / HBM_PEAK_GBS if closest_s > 0 else 0.0,
+                # bytes the lanes ask the caches for (whole node slots and triangle positions); most of them are
+                # served by LDS, L1 and L2: this is a request rate, not memory traffic
+                "requested_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
+                # share of the HBM peak that the measured fabric-side traffic of a launch amounts to
+                "hbm_frac": (traffic / (closest_s / launches) / 1e9) / HBM_PEAK_GBS if traffic and closest_s > 0 else None,
+                "box_tests_per_node_visit": boxes_per_visit,
                 "closest_ms_per_step": [round(s.closest_ms, 3) for s in stats], "shadow_ms_per_step": [round(s.shadow_ms, 3) for s in stats],
                 "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed),
                                       "shading": tot[9].item() / (1e3 * elapsed)},

@@ -477,6 +477,7 @@ static int fill_render(mipt_frame* f, const mipt_camera* cam, const mipt_params*
     R.shardCount = p->shard_count > 1 ? p->shard_count : 1;
     R.shardRank = p->shard_rank;
     R.ownPixelsOnly = (p->own_pixels_only != 0 && R.shardCount > 1) ? 1 : 0;
+    R.countBoxTests = p->count_box_tests != 0;
     if (R.shardRank < 0 || R.shardRank >= R.shardCount) return fail(MIPT_E_INVALID, "shard_rank %d outside 0..%d", p->shard_rank, R.shardCount - 1);
     R.tileSize = p->tile_size > 0 ? p->tile_size : 32;
     R.tilesX = (W + R.tileSize - 1) / R.tileSize;
@@ -607,7 +608,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     // depth 0: primary rays, their surfaces and shadow rays
     launch_raygen(R, f->primQ, st);
     spanBegin(0);
-    launch_closest(S, f->primQ, f->counters + 0, P, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st);
+    launch_closest(S, f->primQ, f->counters + 0, P, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st, false, R.countBoxTests != 0);
     spanEnd();
     launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, f->stats, st);
     spanBegin(1);
@@ -647,7 +648,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     const int32_t* inCount = (level == 1) ? C : Lc - 2;
                     RayQueue cur = f->q[(level - 1) & 1], nxt = f->q[level & 1];
                     spanBegin(0);
-                    launch_closest(S, cur, inCount, (int32_t)slots, Lc + 0, f->hit, R.eps, f->stats, g_numCUs, st, true);
+                    launch_closest(S, cur, inCount, (int32_t)slots, Lc + 0, f->hit, R.eps, f->stats, g_numCUs, st, true, R.countBoxTests != 0);
                     spanEnd();
                     launch_shade_bounce(S, R, cur, f->hit, inCount, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
                                         f->shadowQ, f->shadowBlocks, nxt, Lc + 1, f->stats, st);
@@ -679,7 +680,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         memset(stats, 0, sizeof(*stats));
         unsigned long long h[ST_COUNT];
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
-        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED];
+        stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED]; stats->closest_box_tests = h[ST_CLOSEST_BOXES];
         if (R.ownPixelsOnly) {
             // the stand-in rays of pixels that belong to other shards are no rays of the image: not counted
             int64_t owned = 0;

@@ -78,12 +78,14 @@ struct DevRender {
     int32_t  numSamples;
     int32_t  shardRank, shardCount, tileSize, tilesX;
     int32_t  ownPixelsOnly;   // primary rays of other shards' tiles are replaced by rays that miss the scene
+    int32_t  countBoxTests;   // the closest-hit launches also count the child boxes of the nodes they visit
 };
 
 // ---- statistics slots (uint64 each) ---------------------------------------------------
 enum {
     ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
     ST_SHADOW_CULLED, // shadow rays that were not traced because the direct term they guard is zero
+    ST_CLOSEST_BOXES, // child boxes present in the nodes the closest-hit queries visited (counted on request only)
     ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel, 8 entries
     ST_COUNT = 16
 };
@@ -119,7 +121,7 @@ void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s);
 // closest-hit over q[0 .. *d_count): hit[i] = (t, ua, va, bits triangle id or -1)
 void launch_make_shading(const float4* attr, const int32_t* triMat, const DevMaterial* mats, int64_t n, float4* shade, hipStream_t s);
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
-                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit = false);
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit = false, bool countBoxes = false);
 // any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,

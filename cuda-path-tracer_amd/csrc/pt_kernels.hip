@@ -180,7 +180,7 @@ __device__ __forceinline__ void order_pair(uint32_t& a, uint32_t& b)
     a = lo; b = hi;
 }
 
-template <int MODE, bool BLOCKS>
+template <int MODE, bool BLOCKS, bool COUNT_BOXES = false>
 __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                 const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                 float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     // a lane is at an inner node (cur < leafBase), at a triangle of a leaf (leafBase <= cur < LANE_FINISHED), finished or idle
     auto at_node = [&](uint32_t c) { return c < leafBase; };
     auto at_leaf = [&](uint32_t c) { return c - leafBase < LANE_FINISHED - leafBase; };
-    uint32_t nodeCount = 0, triCount = 0, rayCount = 0;
+    uint32_t nodeCount = 0, triCount = 0, rayCount = 0, boxCount = 0;
 #if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD)
     float ablF = 0.0f, ablG = 0.0f; uint32_t ablU = 0;
 #endif
@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                         asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x));
                     }
                     nodeCount++;
+                    if (COUNT_BOXES) boxCount += (w3.x != MIPT_NO_NODE) + (w3.y != MIPT_NO_NODE) + (w3.z != MIPT_NO_NODE) + (w3.w != MIPT_NO_NODE);
 #ifdef MIPT_ABLATE_VALU
                     // what one more vector instruction per node step costs: MIPT_ABLATE_VALU of them, half v_max_f32, half v_cvt_f32_u32, outside the data flow
                     for (int k = 0; k < MIPT_ABLATE_VALU; k += 2) {
@@ -445,6 +446,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         for (int k = 0; k < 3; k++) { unsigned long long v = wave_sum_u32(hDeep[k]); if (lane == 0) atomicAdd(&stats[ST_PROF + 5 + k], v); }
     }
 #endif
+    if (COUNT_BOXES) { unsigned long long bs = wave_sum_u32(boxCount); if (lane == 0 && bs) atomicAdd(&stats[ST_CLOSEST_BOXES], bs); }
     if (lane == 0 && rs) {
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_RAYS : ST_SHADOW_RAYS], rs);
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_NODES : ST_SHADOW_NODES], ns);
@@ -517,11 +519,15 @@ static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount,
 }
 
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
-                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit)
+                    float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit, bool countBoxes)
 {
     TraceShape t = trace_shape(S, true, maxCount, numCUs, S.numNodeSlots);
-    hipLaunchKernelGGL((k_trace<0, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
-                       (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
+    if (countBoxes)     // the same kernel with one more counter: child boxes that exist in the nodes it visits
+        hipLaunchKernelGGL((k_trace<0, false, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
+                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
+    else
+        hipLaunchKernelGGL((k_trace<0, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
+                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,

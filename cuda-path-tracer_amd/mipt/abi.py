@@ -43,7 +43,7 @@ class Params(C.Structure):
                 ("epsilon", C.c_float), ("normalize_normal_map", C.c_int32), ("seed", C.c_uint32),
                 ("shard_rank", C.c_int32), ("shard_count", C.c_int32), ("tile_size", C.c_int32),
                 ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("chunk_samples", C.c_int32),
-                ("own_pixels_only", C.c_int32)]
+                ("own_pixels_only", C.c_int32), ("count_box_tests", C.c_int32)]
 
 
 class BuildOptions(C.Structure):
@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("closest_triangle_tests", C.c_uint64), ("active_pixels", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("closest_launches", C.c_int32), ("shadow_launches", C.c_int32),
-                ("chunk_samples", C.c_int32), ("samples_done", C.c_int32)]
+                ("chunk_samples", C.c_int32), ("samples_done", C.c_int32), ("closest_box_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

@@ -124,6 +124,8 @@ typedef struct mipt_params {
                                         the FINAL images of the shards add up to the frame.  0: every shard
                                         traces depth 0 for the whole image (needed when the sums are reduced
                                         and finalized on one rank, as sample-range sharding requires) */
+    int32_t  count_box_tests;        /* 1: mipt_stats.closest_box_tests is filled (the closest-hit kernel then counts the
+                                        child boxes that exist in every node it visits; a few percent slower) */
 } mipt_params;
 
 typedef struct mipt_build_options {
@@ -167,6 +169,8 @@ typedef struct mipt_stats {
     int32_t  shadow_launches;
     int32_t  chunk_samples;          /* samples per pass actually used */
     int32_t  samples_done;           /* first-bounce samples summed into d_accum (all of them unless cancelled) */
+    uint64_t closest_box_tests;      /* ray/box tests of the closest-hit queries against child boxes that exist (a node
+                                        visit tests 2..4 of them); 0 unless mipt_params.count_box_tests */
 } mipt_stats;
 
 /* Replaces CPTCallback::UpdateProgress (PTProgress.h:3-7).  Called on the calling

@@ -1,0 +1,78 @@
+"""The sun view (the triangles binned by their direction from the sun, searched by the shadow rays
+instead of the BVH) must give the image the BVH search gives, bit for bit, wherever the sun stands;
+where no view can be built (sun inside the scene's box) the BVH answers and the result is the same."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scenes
+from mipt import host
+
+pytestmark = pytest.mark.gpu
+
+
+def render_both(gpu, scene, cam, sun, **kw):
+    sc = gpu.Scene(scene.desc)
+    on = sc.render(cam, host.default_params(sun_pos=sun, **kw))
+    off = sc.render(cam, host.default_params(sun_pos=sun, disable_sun_view=1, **kw))
+    return on, off
+
+
+def test_preset_sun_uses_the_view_and_matches_the_bvh(gpu, atrium_small):
+    cam, sun = scenes.crytek_camera(div=4)
+    (img, ids, st), (img0, ids0, st0) = render_both(gpu, atrium_small, cam, sun, global_illumination=1, num_samples=4)
+    assert np.array_equal(ids, ids0) and np.array_equal(img, img0)
+    assert st0.shadow_rays_sun_view == 0 and st0.shadow_rays > 0
+    assert st.shadow_rays_sun_view == st.shadow_rays == st0.shadow_rays          # every shadow ray went through the view
+    assert 0 < st.triangle_tests - st.closest_triangle_tests                    # and was answered by triangle tests
+
+
+# the sun straight above, low over the horizon on each side, far away, just outside the box, below the floor
+@pytest.mark.parametrize("sun", [(0.0, 4000.0, 0.0), (6000.0, 2200.0, 300.0), (-200.0, 1900.0, -5000.0), (1e5, 2e5, 3e4),
+                                 (300.0, 1700.0, 100.0), (100.0, -900.0, 50.0)])
+def test_sun_positions_direct_and_gi(gpu, atrium_small, atrium_small_oracle, sun):
+    cam, _ = scenes.crytek_camera(div=8)
+    (img, ids, st), (img0, ids0, st0) = render_both(gpu, atrium_small, cam, sun, global_illumination=1, num_samples=3, use_normals=1)
+    assert np.array_equal(img, img0)
+    assert st.shadow_rays == st0.shadow_rays
+    # and the direct image is the oracle's (brute force over all triangles)
+    prm = host.default_params(sun_pos=sun, global_illumination=0, use_normals=1)
+    sc = gpu.Scene(atrium_small.desc)
+    dimg, dids, dst = sc.render(cam, prm)
+    oimg, _, otri, _ = atrium_small_oracle.render(cam, prm, accel=ob.ACCEL_BRUTE)
+    assert np.array_equal(dids, otri) and np.array_equal(dimg, oimg)
+
+
+def test_sun_inside_the_box_falls_back_to_the_bvh(gpu, atrium_small):
+    cam, _ = scenes.crytek_camera(div=8)
+    (img, ids, st), (img0, ids0, st0) = render_both(gpu, atrium_small, cam, (0.0, 300.0, 0.0), global_illumination=1, num_samples=2)
+    assert st.shadow_rays_sun_view == 0 and st.shadow_rays == st0.shadow_rays
+    assert np.array_equal(img, img0)
+
+
+def test_cornell_small_scale(gpu, cornell, cornell_oracle):
+    cam, sun = scenes.cornell_camera(div=4)
+    (img, ids, st), (img0, ids0, st0) = render_both(gpu, cornell, cam, sun, global_illumination=1, num_samples=8)
+    assert st.shadow_rays_sun_view == st.shadow_rays > 0
+    assert np.array_equal(img, img0)
+
+
+def test_sun_moves_between_calls_of_one_frame(gpu, atrium_small):
+    # the view is rebuilt when set_params moves the sun
+    cam, sun = scenes.crytek_camera(div=8)
+    sc = gpu.Scene(atrium_small.desc)
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=2)
+    frame = gpu.Frame(sc, cam, prm)
+    n = frame.num_pixels
+    acc, out = gpu.DeviceBuffer(n * 12), gpu.DeviceBuffer(n * 12)
+    imgs = []
+    for s in (sun, (2500.0, 3000.0, -800.0), sun):
+        prm = host.default_params(sun_pos=s, global_illumination=1, num_samples=2)
+        frame.set_params(cam, prm)
+        st = frame.accumulate(acc.ptr)
+        frame.finalize(acc.ptr, out.ptr)
+        assert st.shadow_rays_sun_view == st.shadow_rays
+        imgs.append(out.to_host().copy())
+        ref = sc.render(cam, host.default_params(sun_pos=s, global_illumination=1, num_samples=2, disable_sun_view=1))[0]
+        assert np.array_equal(imgs[-1].reshape(ref.shape), ref)
+    assert np.array_equal(imgs[0], imgs[2]) and not np.array_equal(imgs[0], imgs[1])
