@@ -311,7 +311,7 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
     // depth-first walk of a tree whose nodes push up to (width - 1) siblings per level
-    D.stackDepth = (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2 + (MIPT_NODE_WIDTH - 1);     // + spare entries a node step may scribble on
+    D.stackDepth = (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2 + MIPT_NODE_WIDTH;     // + spare entries a node step may scribble on
     D.stackLds = D.stackDepth < MIPT_STACK_LDS_MAX ? D.stackDepth : MIPT_STACK_LDS_MAX;
     if (const char* e = getenv("MIPT_STACK_LDS")) {          // test hook: a small LDS part sends the stack through its global-memory slice
         int v = atoi(e);

@@ -161,8 +161,12 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32
 // entries of a node are sorted with integer min/max alone, and cutting the low bits of a key off
 // rounds it down.  That keeps the second use of the key safe: when a closest-hit entry is popped and
 // its (rounded down) entry distance lies beyond the best hit found meanwhile, the child is dropped
-// without being fetched.  A child that was missed is ENTRY_MISS, above every entry of a hit.
-#define ENTRY_MISS 0x7fffffffu
+// without being fetched.  A child that was missed is ENTRY_MISS, below every entry of a hit: the four
+// entries are sorted in DESCENDING order (farthest child first, nearest last, misses behind it) and
+// stored on the stack as they stand, so the children that were hit end up below the new top with the
+// nearest one on top, and the next node to visit is popped like any other entry.
+#define ENTRY_MISS 0u
+#define CULL_NONE  0x7fffffffu     // no hit yet: every entry passes
 template <int MODE>
 __device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t slotMask, int& hits)
 {
@@ -170,14 +174,14 @@ __device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint
     bool h = box_test(r, wx, wy, wz, tcull, t0, t1);
     hits += h;
     uint32_t key = (MODE != 0) ? 0x7f7fffffu - __float_as_uint(t1 - t0) : __float_as_uint(t0);
-    uint32_t e = (code & slotMask) | (key & ~slotMask);
+    uint32_t e = code | (key & ~slotMask);      // codes of children that exist are below slotMask; a child that does not exist is always missed
     return h ? e : ENTRY_MISS;
 }
-// compare-exchange: afterwards a <= b
+// compare-exchange: afterwards a >= b
 __device__ __forceinline__ void order_pair(uint32_t& a, uint32_t& b)
 {
     uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-    a = lo; b = hi;
+    a = hi; b = lo;
 }
 
 template <int MODE, bool BLOCKS, bool COUNT_BOXES = false>
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
     BoxRay br = {};
     float tcull = FLT_MAX;
-    uint32_t cullEntry = ENTRY_MISS;        // entries above this one lie beyond the best hit: bits of tcull with the code bits all set
+    uint32_t cullEntry = CULL_NONE;        // entries above this one lie beyond the best hit: bits of tcull with the code bits all set
     Hit best; best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
     // result of a finished ray
     auto write_result = [&]() {
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                     o = f3(o4.x, o4.y, o4.z); d = f3(d4.x, d4.y, d4.z);
                     tag0 = __float_as_int(o4.w); tag1 = __float_as_int(d4.w);
                     br = make_box_ray(S, o, d);
-                    tcull = FLT_MAX; cullEntry = ENTRY_MISS;
+                    tcull = FLT_MAX; cullEntry = CULL_NONE;
                     best.t = FLT_MAX; best.u = 0; best.v = 0; best.tri = -1;
                     sp = 0;
                     rayCount++;
@@ -358,27 +362,20 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                     int hits = 0;
                     uint32_t e0 = box_entry<MODE>(br, w0.x, w0.y, w0.z, tcull, w3.x, slotMask, hits), e1 = box_entry<MODE>(br, w0.w, w1.x, w1.y, tcull, w3.y, slotMask, hits);
                     uint32_t e2 = box_entry<MODE>(br, w1.z, w1.w, w2.x, tcull, w3.z, slotMask, hits), e3 = box_entry<MODE>(br, w2.y, w2.z, w2.w, tcull, w3.w, slotMask, hits);
-                    // five compare-exchanges sort the four entries
+                    // five compare-exchanges sort the four entries, largest (farthest) first
                     order_pair(e0, e1); order_pair(e2, e3);
                     order_pair(e0, e2); order_pair(e1, e3);
                     order_pair(e1, e2);
-                    // The children that were hit are the first `hits`; the nearest is visited now, the
-                    // others go on the stack, farthest deepest: child j lands at sp + hits - 1 - j.  For a
-                    // child that was missed that offset is negative; taken modulo 4 it points above the
-                    // new top of the stack, where the value is never read.  All three stores can thus be
-                    // unconditional (the stack has three spare entries).
-                    int p1 = sp + ((hits - 2) & 3), p2 = sp + ((hits - 3) & 3), p3 = sp + ((hits - 4) & 3);
+                    // all four go on the stack as they stand (four spare entries): the `hits` children that were hit below the new top
                     if (__builtin_expect(__ballot(sp + 3 >= ldsCap) == 0, 1)) {
-                        stack[p1 * WAVE] = e1; stack[p2 * WAVE] = e2; stack[p3 * WAVE] = e3;
+                        uint32_t* st = stack + sp * WAVE;
+                        st[0] = e0; st[WAVE] = e1; st[2 * WAVE] = e2; st[3 * WAVE] = e3;
                     } else {
-                        stack_store(stack, spill, ldsCap, p1, e1); stack_store(stack, spill, ldsCap, p2, e2); stack_store(stack, spill, ldsCap, p3, e3);
+                        stack_store(stack, spill, ldsCap, sp, e0); stack_store(stack, spill, ldsCap, sp + 1, e1);
+                        stack_store(stack, spill, ldsCap, sp + 2, e2); stack_store(stack, spill, ldsCap, sp + 3, e3);
                     }
-                    if (hits > 0) {
-                        sp += hits - 1;
-                        cur = e0 & slotMask;
-                    } else {
-                        cur = pop();
-                    }
+                    sp += hits;
+                    cur = pop();
                 }
             } while (__popcll(__ballot(at_node(cur))) > stay);
         };
