@@ -137,8 +137,8 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 #define TRACE_WAVES 12            // waves per workgroup
 #define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
 #define TRACE_TRI_VOTE 16
-#define TRACE_NODE_DROP 40
-#define TRACE_TRI_STAY 2      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
+#define TRACE_NODE_DROP 28
+#define TRACE_TRI_STAY 3      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
 #define LANE_FINISHED 0x7FFFFFFEu   // ray done, result not yet written
 #define LANE_IDLE     0x7FFFFFFFu   // no ray; every child code is below LANE_FINISHED
 

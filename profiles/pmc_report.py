@@ -13,7 +13,14 @@ for r in rows:
         print("  wave instrs: VALU %.3g SALU %.3g VMEM_RD %.3g LDS %.3g" % (f("SQ_INSTS_VALU"), f("SQ_INSTS_SALU"), f("SQ_INSTS_VMEM_RD"), f("SQ_INSTS_LDS")))
         print("  wave time: waiting %.2f, issue-stalled %.2f, issuing %.2f" % (f("SQ_WAIT_ANY") / wc, f("SQ_WAIT_INST_ANY") / wc, f("SQ_ACTIVE_INST_ANY") / wc))
         print("  resident waves per SIMD          %.2f" % (4 * wc / cyc / 1024))
-        print("  VALU issue, INSTS_VALU x 4 cycles over SIMD cycles (upper estimate: simple ops measure 2.2-2.7 cycles) %.2f" % (f("SQ_INSTS_VALU") * 4 / 1024 / cyc))
+        # a wave64 vector instruction occupies its SIMD for 2 cycles (measured on this kernel: 2.4 cycles per added
+        # instruction, profiles/r02_bound_ablation.md); SIMD cycles = 4 SIMDs x 256 CUs x cycles
+        print("  VALU issue, INSTS_VALU x 2.4 cycles over SIMD cycles %.2f   (x 2 cycles, the floor: %.2f)" % (
+            f("SQ_INSTS_VALU") * 2.4 / 1024 / cyc, f("SQ_INSTS_VALU") * 2 / 1024 / cyc))
+        if f("SQ_INST_CYCLES_VALU"):
+            print("  SQ_INST_CYCLES_VALU x 4 over SIMD cycles %.2f, SQ_BUSY_CU_CYCLES share %.2f, TA address FIFO full %.3g, TA command FIFO full %.3g, LDS bank conflict share of LDS cycles %.2f" % (
+                f("SQ_INST_CYCLES_VALU") * 4 / 1024 / cyc, f("SQ_BUSY_CU_CYCLES") / max(f("SQ_CYCLES"), 1), f("SQ_VMEM_TA_ADDR_FIFO_FULL"), f("SQ_VMEM_TA_CMD_FIFO_FULL"),
+                f("SQ_LDS_BANK_CONFLICT") / max(f("SQ_LDS_IDX_ACTIVE"), 1)))
         print("  TA busy                          %.2f" % (f("TA_BUSY_avr") / cyc))
         print("  L1 accesses %.3g, L1->L2 %.3g (L1 hit %.2f), L2 hit %.2f, fabric reads %.3g, FETCH_SIZE %.1f GB, WRITE_SIZE %.2f GB" % (
             f("TCP_TOTAL_CACHE_ACCESSES_sum"), f("TCP_TCC_READ_REQ_sum"), 1 - f("TCP_TCC_READ_REQ_sum") / max(f("TCP_TOTAL_CACHE_ACCESSES_sum"), 1),

@@ -330,3 +330,15 @@ def test_tile_shards_that_finalize_their_own_pixels(gpu, cornell):
     assert np.array_equal(total, ref) and np.array_equal(ids, ref_ids)
     # no duplicated work, and the stand-in rays of pixels of other shards are not counted
     assert rays == st_full.closest_rays + st_full.shadow_rays + st_full.shadow_rays_culled
+
+
+def test_box_tests_are_counted_on_request(gpu, atrium_small):
+    # mipt_params.count_box_tests: the closest-hit kernel also counts the child boxes that exist in the nodes it visits
+    cam, sun = scenes.crytek_camera(div=8)
+    sc = gpu.Scene(atrium_small.desc)
+    img0, ids0, st0 = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=2))
+    img1, ids1, st1 = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=2, count_box_tests=1))
+    assert st0.closest_box_tests == 0
+    assert st1.closest_node_visits == st0.closest_node_visits > 0
+    assert 2 * st1.closest_node_visits <= st1.closest_box_tests <= 4 * st1.closest_node_visits
+    assert np.array_equal(img0, img1) and np.array_equal(ids0, ids1)
