@@ -33,7 +33,7 @@ if len(sys.argv) > 3:
     import json
     out, workload = sys.argv[2], sys.argv[3]
     for r in rows:
-        if "k_trace<0" in r["kernel"]:
+        if "k_trace<0, false, false>" in r["kernel"]:      # the timed instance (the counting instance runs once more, untimed)
             calls = float(r["calls"])
             fetch, write = float(r["FETCH_SIZE"]) * 1024, float(r["WRITE_SIZE"]) * 1024
             try:
