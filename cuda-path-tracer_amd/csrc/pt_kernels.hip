@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     auto at_node = [&](uint32_t c) { return c < leafBase; };
     auto at_leaf = [&](uint32_t c) { return c - leafBase < LANE_FINISHED - leafBase; };
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0, boxCount = 0;
-#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD)
+#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD) || defined(MIPT_ABLATE_FMAMIX)
     float ablF = 0.0f, ablG = 0.0f; uint32_t ablU = 0;
 #endif
 #ifdef MIPT_TRACE_PROFILE
@@ -346,6 +346,11 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                         asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(w3.x));
                     }
 #endif
+#ifdef MIPT_ABLATE_FMAMIX
+                    // the same for v_fma_mix_f32 (an FMA that converts a 16-bit float operand on the way)
+                    for (int k = 0; k < MIPT_ABLATE_FMAMIX; k++)
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(ablF) : "v"(w3.x), "v"(tcull));
+#endif
 #ifdef MIPT_ABLATE_LOAD
                     // what one more 16-byte load of the node's own cache line costs (lanes that read the node from memory only)
                     if (cur >= (uint32_t)cacheSlots) {
@@ -426,7 +431,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         }
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
-#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD)
+#if defined(MIPT_ABLATE_VALU) || defined(MIPT_ABLATE_LOAD) || defined(MIPT_ABLATE_FMAMIX)
     if (ablF + ablG == 12345.678f && ablU == 0x12345u) stats[ST_PROF] = 1;      // keeps the extra work alive
 #endif
 #ifdef MIPT_TRACE_PROFILE

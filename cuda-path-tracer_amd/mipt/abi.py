@@ -73,7 +73,7 @@ class Stats(C.Structure):
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)
 
 # every symbol include/mipt.h declares
-E_CANCELLED = -5
+E_INVALID, E_DEVICE, E_NOMEM, E_LIMIT, E_CANCELLED = -1, -2, -3, -4, -5     # MIPT_E_* of include/mipt.h
 TRACE_DEVICE_MAX_RAYS = 1 << 18
 
 MIPT_SYMBOLS = [

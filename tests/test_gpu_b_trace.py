@@ -114,3 +114,17 @@ def test_stack_slice_in_global_memory(gpu, atrium_small, atrium_small_oracle, mo
     sc = gpu.Scene(atrium_small.desc)
     monkeypatch.delenv("MIPT_STACK_LDS")
     assert_trace_parity(sc, atrium_small_oracle, scenes.random_rays(atrium_small, 20000, seed=11))
+
+
+def test_ray_count_beyond_the_queue_index_is_refused(gpu, cornell):
+    # the queue head is a 32-bit counter that the persistent waves push past the ray count by up to one
+    # reservation each: counts that could make it wrap are refused before anything is allocated or read
+    import ctypes as C
+    from mipt import abi
+    from mipt.device import lib
+    sc = gpu.Scene(cornell.desc)
+    rays = np.zeros(6, dtype=np.float32)
+    for n in ((1 << 31) - 64, (1 << 31), (1 << 40)):
+        rc = lib().mipt_trace_rays(sc._h, rays.ctypes.data, C.c_int64(n), C.c_float(1e-20), None, None, None)
+        assert rc == abi.E_LIMIT, (n, rc)
+    assert b"too many rays" in lib().mipt_last_error()
