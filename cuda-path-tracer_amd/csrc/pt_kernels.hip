@@ -107,9 +107,10 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // ---------------------------------------------------------------------------------------
 // Traversal kernels: TraceRays / Intersect of PathTracer.cu:193-288 over a queue of rays.
 //
-// One wave per workgroup, one ray per lane, per-lane stack in LDS (entry k of lane l at
-// stack[k * 64 + l]: every lane of a half-wave hits its own bank; entries beyond the LDS part,
-// which only very deep trees need, live in a per-wave slice of global memory).  Waves are
+// One ray per lane, per-lane stack in LDS (entry k of lane l at stack[k * 64 + l]: every lane of a
+// half-wave hits its own bank; entries beyond the LDS part, which only very deep trees need, live in
+// a per-wave slice of global memory).  TRACE_WAVES waves form a workgroup that shares a copy of the
+// first TRACE_CACHE_SLOTS node slots (the top of the tree) in LDS and nothing else.  Waves are
 // persistent: a wave reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands
 // them to its lanes as soon as they fall idle.  The queue is either dense (entries 0 .. count-1) or
 // in blocks of 1 << MIPT_QBLOCK_SHIFT entries of which the first blockCount[b] are valid (the
@@ -123,10 +124,10 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // lanes that wait at a triangle, entered when `triVote` of them do or no lane is at an inner node
 // and repeated while more than `triStay` eighths of them are still at a leaf.  Lanes of the other
 // kind sit a phase out.  A round runs the node phase and then the triangle phase.  A node step
-// fetches one 64-byte node (one cache line per lane), tests its four child boxes, sorts the
-// children that were hit (closest hit: by entry distance; any hit: longest way through the box
-// first), continues with the first and pushes the others.
-// The thresholds were chosen by measurement (profiles/).
+// fetches one 64-byte node (one cache line per lane, or from the copy in LDS), tests its four child
+// boxes, sorts the four stack entries (closest hit: by entry distance; any hit: longest way through
+// the box first; see box_entry), stores all of them and pops the next node.
+// The thresholds were chosen by measurement (profiles/sweep_thresholds.sh).
 //
 // Closest hit (MODE 0): the accepted triangle with the smallest t below FLT_MAX, equal t ->
 // lowest global triangle id; hit[i] = (t, ua, va, id or -1).
