@@ -521,10 +521,21 @@ static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount,
     return t;
 }
 
+// The workgroups ask for more than 64 KiB of LDS: said once per kernel and device, before the first launch.
+template <typename K> static void allow_large_lds(K kernel)
+{
+    static bool done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || done[dev]) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done[dev] = true;
+}
+
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                     float4* hit, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s, bool tagInHit, bool countBoxes)
 {
     TraceShape t = trace_shape(S, true, maxCount, numCUs, S.numNodeSlots);
+    allow_large_lds(k_trace<0, false, true>); allow_large_lds(k_trace<0, false, false>);
     if (countBoxes)     // the same kernel with one more counter: child boxes that exist in the nodes it visits
         hipLaunchKernelGGL((k_trace<0, false, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
                            (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
@@ -539,6 +550,7 @@ void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const 
     TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
     int chunk = trace_chunk();
     if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK;   // must divide a block
+    allow_large_lds(k_trace<1, true, false>); allow_large_lds(k_trace<1, false, false>);
     if (d_blockCount)
         hipLaunchKernelGGL((k_trace<1, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head,
                            (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
@@ -550,6 +562,7 @@ void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, 
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
 {
     TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
+    allow_large_lds(k_trace<2, false, false>);
     hipLaunchKernelGGL((k_trace<2, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
                        (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
 }
