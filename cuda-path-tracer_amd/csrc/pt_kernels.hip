@@ -789,32 +789,38 @@ void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* h
 }
 
 // ---------------------------------------------------------------------------------------
-// first-bounce rays, CPUPathTracer.cpp:417-428 at depth 0: slot = s * nAct + a
+// first-bounce rays, CPUPathTracer.cpp:417-428 at depth 0: slot = s * nAct + a.  A thread makes
+// GEN_SAMPLES consecutive samples of one active pixel: the pixel's state is read once for all of
+// them, and the 64 lanes of a wave write 64 consecutive slots of every sample.
+#define GEN_SAMPLES 8
 __global__ void __launch_bounds__(256) k_gen_first(DevRender R, const float4* __restrict__ pixState,
                                                   const int32_t* __restrict__ actPix, int32_t nAct, int32_t n0,
                                                   int32_t Sn, RayQueue q)
 {
-    int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (int64_t)nAct * Sn) return;
-    int a = (int)(slot % nAct), s = (int)(slot / nAct);
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nAct) return;
     int p = actPix[a];
-    uint32_t n = (uint32_t)(n0 + s);
     float4 s1 = pixState[(size_t)p * 4 + 1], s2 = pixState[(size_t)p * 4 + 2], s3 = pixState[(size_t)p * 4 + 3];
     F3 hp = f3(s1.x, s1.y, s1.z), N = f3(s2.x, s2.y, s2.z), Nt = f3(s2.w, s3.x, s3.y);
     F3 Nb = f3cross(N, Nt);
-    float r1 = rng_u01(R.seed, (uint32_t)p, n, 0, 0), r2 = rng_u01(R.seed, (uint32_t)p, n, 0, 1);
-    F3 sw = to_world(sample_hemisphere(r1, r2), N, Nt, Nb);
-    F3 o = f3add(hp, f3scale(sw, PT_BIAS));
-    q.o[slot] = make_float4(o.x, o.y, o.z, __int_as_float((int)slot));
-    q.d[slot] = make_float4(sw.x, sw.y, sw.z, 0.0f);
+    const int sEnd = min((int)(blockIdx.y + 1) * GEN_SAMPLES, Sn);
+    for (int s = blockIdx.y * GEN_SAMPLES; s < sEnd; s++) {
+        int64_t slot = (int64_t)s * nAct + a;
+        uint32_t n = (uint32_t)(n0 + s);
+        float r1 = rng_u01(R.seed, (uint32_t)p, n, 0, 0), r2 = rng_u01(R.seed, (uint32_t)p, n, 0, 1);
+        F3 sw = to_world(sample_hemisphere(r1, r2), N, Nt, Nb);
+        F3 o = f3add(hp, f3scale(sw, PT_BIAS));
+        store_stream(&q.o[slot], make_float4(o.x, o.y, o.z, __int_as_float((int)slot)));
+        store_stream(&q.d[slot], make_float4(sw.x, sw.y, sw.z, 0.0f));
+    }
 }
 
 void launch_gen_first_bounce(const DevRender& R, const float4* pixState, const int32_t* actPix, int32_t nAct,
                              int32_t n0, int32_t Sn, RayQueue q, hipStream_t s)
 {
-    int64_t n = (int64_t)nAct * Sn;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_gen_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, R, pixState, actPix, nAct, n0, Sn, q);
+    if (nAct <= 0 || Sn <= 0) return;
+    hipLaunchKernelGGL(k_gen_first, dim3((unsigned)((nAct + 255) / 256), (unsigned)((Sn + GEN_SAMPLES - 1) / GEN_SAMPLES)), dim3(256), 0, s,
+                       R, pixState, actPix, nAct, n0, Sn, q);
 }
 
 // ---------------------------------------------------------------------------------------
