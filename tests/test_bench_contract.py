@@ -7,8 +7,8 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r02_a_bench_line.json")
-STATS = os.path.join(ROOT, "profiles", "r02_a_bench_kernel_stats.csv")
+LINE = os.path.join(ROOT, "profiles", "r02_b_bench_line.json")
+STATS = os.path.join(ROOT, "profiles", "r02_b_bench_kernel_stats.csv")
 
 
 def load_line():
