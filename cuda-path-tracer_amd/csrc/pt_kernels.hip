@@ -347,6 +347,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                         asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(w3.x));
                     }
 #endif
+#ifdef MIPT_ABLATE_SALU
+                    // the same for scalar instructions (on a register nothing else uses)
+                    for (int k = 0; k < MIPT_ABLATE_SALU; k++) asm volatile("s_add_u32 s90, s90, 1" : : : "s90", "scc");
+#endif
 #ifdef MIPT_ABLATE_FMAMIX
                     // the same for v_fma_mix_f32 (an FMA that converts a 16-bit float operand on the way)
                     for (int k = 0; k < MIPT_ABLATE_FMAMIX; k++)
