@@ -347,6 +347,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                         asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(w3.x));
                     }
 #endif
+#ifdef MIPT_ABLATE_SLEEP
+                    // the wave sleeps 64 * MIPT_ABLATE_SLEEP cycles per node step without issuing anything: what a longer step costs when nothing else changes
+                    __builtin_amdgcn_s_sleep(MIPT_ABLATE_SLEEP);
+#endif
 #ifdef MIPT_ABLATE_SALU
                     // the same for scalar instructions (on a register nothing else uses)
                     for (int k = 0; k < MIPT_ABLATE_SALU; k++) asm volatile("s_add_u32 s90, s90, 1" : : : "s90", "scc");
