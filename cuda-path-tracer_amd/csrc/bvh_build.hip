@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(256) k_collapse_level(const uint4* __restrict_
     }
     const int depth = depthOf[x];
     int mate = -1;
+#if MIPT_NODE_WIDTH == 4
     if ((slot & 1u) == 0) {                            // first slot of a line: the largest inner child shares the line
         float mateArea = -1.0f;
         for (int i = 0; i < n; i++) {
@@ -539,28 +540,30 @@ __global__ void __launch_bounds__(256) k_collapse_level(const uint4* __restrict_
             if (ar > mateArea) { mateArea = ar; mate = i; }
         }
     }
-    uint32_t words[16];
+#endif
+    uint32_t words[4 * MIPT_NODE_WIDTH];
     for (int i = 0; i < MIPT_NODE_WIDTH; i++) {
         if (i < n) {
             words[3 * i] = k[i].w[0]; words[3 * i + 1] = k[i].w[1]; words[3 * i + 2] = k[i].w[2];
             uint32_t code = k[i].code;
             if (!(code & MIPT_LEAF_BIT)) {
+#if MIPT_NODE_WIDTH == 4
                 uint32_t cs = (i == mate) ? slot + 1 : 2u * (uint32_t)atomicAdd(&cc->lines, 1);
+#else
+                uint32_t cs = (uint32_t)atomicAdd(&cc->lines, 1);        // a 128-byte slot is a line of its own
+#endif
                 slotOf[code] = cs;
                 depthOf[code] = depth + 1;
                 code = cs;
             }
-            words[12 + i] = code;
+            words[3 * MIPT_NODE_WIDTH + i] = code;
         } else {
             words[3 * i] = words[3 * i + 1] = words[3 * i + 2] = 0x0000FFFFu;    // min above max: no ray enters an unused child
-            words[12 + i] = MIPT_NO_NODE;
+            words[3 * MIPT_NODE_WIDTH + i] = MIPT_NO_NODE;
         }
     }
-    uint4* o = wide + (size_t)slot * 4;
-    o[0] = make_uint4(words[0], words[1], words[2], words[3]);
-    o[1] = make_uint4(words[4], words[5], words[6], words[7]);
-    o[2] = make_uint4(words[8], words[9], words[10], words[11]);
-    o[3] = make_uint4(words[12], words[13], words[14], words[15]);
+    uint4* o = wide + (size_t)slot * MIPT_NODE_U4;
+    for (int i = 0; i < MIPT_NODE_U4; i++) o[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
     atomicMax(&cc->maxDepth, depth + 1);
     atomicAdd(&cc->numWide, 1);
 }
@@ -577,17 +580,22 @@ static int collapse_to_wide(BvhResult* out, const std::vector<int32_t>& levelEnd
     const int64_t oldSlots = out->numNodeSlots;
     if (oldSlots <= 0 || (out->rootCode & MIPT_LEAF_BIT)) { out->numInner = 0; out->maxDepth = 0; return MIPT_OK; }
     const int64_t inner2 = (oldSlots - 1) / 2;
-    const int64_t capSlots = 2 * (inner2 + 1);          // every wide node alone in its line: cannot be exceeded
+#if MIPT_NODE_WIDTH == 4
+    const int64_t slotsPerLine = 2;
+#else
+    const int64_t slotsPerLine = 1;
+#endif
+    const int64_t capSlots = slotsPerLine * (inner2 + 1);          // every wide node alone in its line: cannot be exceeded
     uint32_t* slotOf = nullptr; int32_t* depthOf = nullptr; uint4* wide = nullptr; CollapseCounters* cc = nullptr;
     CollapseCounters h = {};
     int rc = MIPT_OK;
     hipError_t e = hipSuccess;
     auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     tryq(hipMalloc(&slotOf, 4 * (size_t)oldSlots)); tryq(hipMalloc(&depthOf, 4 * (size_t)oldSlots));
-    tryq(hipMalloc(&wide, 64 * (size_t)capSlots)); tryq(hipMalloc(&cc, sizeof(CollapseCounters)));
+    tryq(hipMalloc(&wide, 16 * MIPT_NODE_U4 * (size_t)capSlots)); tryq(hipMalloc(&cc, sizeof(CollapseCounters)));
     if (e == hipSuccess) {
         tryq(hipMemsetAsync(slotOf, 0xFF, 4 * (size_t)oldSlots, stream));
-        tryq(hipMemsetAsync(wide, 0, 64 * (size_t)capSlots, stream));
+        tryq(hipMemsetAsync(wide, 0, 16 * MIPT_NODE_U4 * (size_t)capSlots, stream));
         hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(1), 0, stream, slotOf, depthOf, cc);
         int32_t first = 0;
         for (size_t d = 0; d < levelEnd.size(); d++) {
@@ -602,10 +610,10 @@ static int collapse_to_wide(BvhResult* out, const std::vector<int32_t>& levelEnd
         tryq(hipGetLastError());
     }
     if (e == hipSuccess) {
-        const int64_t used = 2 * (int64_t)h.lines;
+        const int64_t used = slotsPerLine * (int64_t)h.lines;
         uint4* fit = nullptr;
-        if (used < capSlots && hipMalloc(&fit, 64 * (size_t)used) == hipSuccess) {      // give the unused tail back
-            tryq(hipMemcpy(fit, wide, 64 * (size_t)used, hipMemcpyDeviceToDevice));
+        if (used < capSlots && hipMalloc(&fit, 16 * MIPT_NODE_U4 * (size_t)used) == hipSuccess) {      // give the unused tail back
+            tryq(hipMemcpy(fit, wide, 16 * MIPT_NODE_U4 * (size_t)used, hipMemcpyDeviceToDevice));
             (void)hipFree(wide);
             wide = fit;
         }
@@ -613,7 +621,7 @@ static int collapse_to_wide(BvhResult* out, const std::vector<int32_t>& levelEnd
     if (e == hipSuccess) {
         (void)hipFree(out->nodes);
         out->nodes = wide; wide = nullptr;
-        out->numNodeSlots = 2 * (int64_t)h.lines;
+        out->numNodeSlots = slotsPerLine * (int64_t)h.lines;
         out->numInner = h.numWide;
         out->maxDepth = h.maxDepth;
     } else {
@@ -632,9 +640,11 @@ __global__ void __launch_bounds__(256) k_unify_codes(uint4* wide, int64_t numSlo
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= numSlots) return;
-    uint4 c = wide[i * 4 + 3];
     auto fix = [&](uint32_t x) { return (x != MIPT_NO_NODE && (x & MIPT_LEAF_BIT)) ? leafBase + (x & ~MIPT_LEAF_BIT) : x; };
-    wide[i * 4 + 3] = make_uint4(fix(c.x), fix(c.y), fix(c.z), fix(c.w));
+    for (int k = 3 * MIPT_NODE_WIDTH / 4; k < MIPT_NODE_U4; k++) {      // the uint4 that hold the child codes
+        uint4 c = wide[i * MIPT_NODE_U4 + k];
+        wide[i * MIPT_NODE_U4 + k] = make_uint4(fix(c.x), fix(c.y), fix(c.z), fix(c.w));
+    }
 }
 
 void mipt_free_bvh(BvhResult* r)

@@ -24,7 +24,10 @@
 #ifndef MIPT_TRI_F4
 #define MIPT_TRI_F4 4      // 64-byte records: a record never straddles a 128-byte line
 #endif
-#define MIPT_NODE_WIDTH 4
+#ifndef MIPT_NODE_WIDTH
+#define MIPT_NODE_WIDTH 4      // children per node slot: 4 (64-byte slots) or 8 (128-byte slots: words 3k .. 3k+2 = box of child k, words 24 .. 31 = child codes)
+#endif
+#define MIPT_NODE_U4 MIPT_NODE_WIDTH   // uint4 per node slot
 #define MIPT_STACK_LDS_MAX 16   // stack entries (4 bytes) per lane kept in LDS (4 KiB per wave); deeper entries, which one node visit in ten thousand needs, go to the spill slice
 #define MIPT_SHADE_F4 8
 // A queue in blocks: entries [b << MIPT_QBLOCK_SHIFT, (b << MIPT_QBLOCK_SHIFT) + blockCount[b]) of every block b are valid

@@ -136,7 +136,7 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
 #define TRACE_WAVES 12            // waves per workgroup
-#define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
+#define TRACE_CACHE_SLOTS (2048 / MIPT_NODE_WIDTH)     // node slots copied to LDS per workgroup (32 KiB)
 #define TRACE_TRI_VOTE 16
 #define TRACE_NODE_DROP 28
 #define TRACE_TRI_STAY 3      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
@@ -200,9 +200,9 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     const int ldsCap = S.stackLds;
     const uint4* __restrict__ nodes = S.nodes;
     const uint32_t leafBase = S.leafBase, slotMask = S.slotMask;
-    for (int i = threadIdx.x; i < cacheSlots * 4; i += blockDim.x) smem4[i] = nodes[i];
+    for (int i = threadIdx.x; i < cacheSlots * MIPT_NODE_U4; i += blockDim.x) smem4[i] = nodes[i];
     __syncthreads();
-    uint32_t* stack = (uint32_t*)(smem4 + (size_t)cacheSlots * 4) + (size_t)waveInGroup * ldsCap * WAVE + lane;
+    uint32_t* stack = (uint32_t*)(smem4 + (size_t)cacheSlots * MIPT_NODE_U4) + (size_t)waveInGroup * ldsCap * WAVE + lane;
     const int n = *d_count;
     // per-wave slice of the spill area
     const size_t waveId = (size_t)blockIdx.x * (blockDim.x / WAVE) + waveInGroup;
@@ -326,25 +326,34 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                 pNodeIters++;
 #endif
                 if (at_node(cur)) {
-                    uint4 w0, w1, w2, w3;
+                    // the node slot as words: 3k .. 3k+2 = box of child k, 3W .. 4W-1 = child codes (W = MIPT_NODE_WIDTH)
+                    uint4 q4[MIPT_NODE_U4];
                     if (cur < (uint32_t)cacheSlots) {       // the top of the tree is read from the workgroup's copy in LDS
-                        const uint4* nd = smem4 + cur * 4;
-                        w0 = nd[0]; w1 = nd[1]; w2 = nd[2]; w3 = nd[3];
+                        const uint4* nd = smem4 + cur * MIPT_NODE_U4;
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_U4; k++) q4[k] = nd[k];
                         // keeps the two kinds of load apart: merged into one flat load they would all go through the
-                        // vector memory pipeline, which is what the copy in LDS is there to relieve
-                        asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x));
+                        // vector memory pipeline
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_U4; k++) asm volatile("" : "+v"(q4[k].x));
                     } else {
-                        const uint4* nd = nodes + (size_t)cur * 4;
-                        w0 = nd[0]; w1 = nd[1]; w2 = nd[2]; w3 = nd[3];
-                        asm volatile("" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x));
+                        const uint4* nd = nodes + (size_t)cur * MIPT_NODE_U4;
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_U4; k++) q4[k] = nd[k];
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_U4; k++) asm volatile("" : "+v"(q4[k].x));
                     }
+                    auto word = [&](int i) -> uint32_t { const uint4& v = q4[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
                     nodeCount++;
-                    if (COUNT_BOXES) boxCount += (w3.x != MIPT_NO_NODE) + (w3.y != MIPT_NO_NODE) + (w3.z != MIPT_NO_NODE) + (w3.w != MIPT_NO_NODE);
+                    if (COUNT_BOXES) {
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_WIDTH; k++) boxCount += word(3 * MIPT_NODE_WIDTH + k) != MIPT_NO_NODE;
+                    }
 #ifdef MIPT_ABLATE_VALU
                     // what one more vector instruction per node step costs: MIPT_ABLATE_VALU of them, half v_max_f32, half v_cvt_f32_u32, outside the data flow
                     for (int k = 0; k < MIPT_ABLATE_VALU; k += 2) {
                         asm volatile("v_max_f32 %0, %0, %1" : "+v"(ablF) : "v"(tcull));
-                        asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(w3.x));
+                        asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(ablG) : "v"(q4[0].x));
                     }
 #endif
 #ifdef MIPT_ABLATE_SLEEP
@@ -358,14 +367,14 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_ABLATE_FMAMIX
                     // the same for v_fma_mix_f32 (an FMA that converts a 16-bit float operand on the way)
                     for (int k = 0; k < MIPT_ABLATE_FMAMIX; k++)
-                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(ablF) : "v"(w3.x), "v"(tcull));
+                        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(ablF) : "v"(q4[0].x), "v"(tcull));
 #endif
 #ifdef MIPT_ABLATE_LOAD
                     // what one more 16-byte load of the node's own cache line costs (lanes that read the node from memory only)
                     if (cur >= (uint32_t)cacheSlots) {
                         const uint4* alias = nodes;
                         asm volatile("" : "+s"(alias));
-                        for (int k = 0; k < MIPT_ABLATE_LOAD; k++) ablU ^= alias[(size_t)cur * 4 + (k & 3)].y;
+                        for (int k = 0; k < MIPT_ABLATE_LOAD; k++) ablU ^= alias[(size_t)cur * MIPT_NODE_U4 + (k & 3)].y;
                     }
 #endif
 #ifdef MIPT_TRACE_HIST
@@ -374,19 +383,31 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #endif
                     // one entry per child, ENTRY_MISS where the ray misses the child's box
                     int hits = 0;
-                    uint32_t e0 = box_entry<MODE>(br, w0.x, w0.y, w0.z, tcull, w3.x, slotMask, hits), e1 = box_entry<MODE>(br, w0.w, w1.x, w1.y, tcull, w3.y, slotMask, hits);
-                    uint32_t e2 = box_entry<MODE>(br, w1.z, w1.w, w2.x, tcull, w3.z, slotMask, hits), e3 = box_entry<MODE>(br, w2.y, w2.z, w2.w, tcull, w3.w, slotMask, hits);
-                    // five compare-exchanges sort the four entries, largest (farthest) first
-                    order_pair(e0, e1); order_pair(e2, e3);
-                    order_pair(e0, e2); order_pair(e1, e3);
-                    order_pair(e1, e2);
-                    // all four go on the stack as they stand (four spare entries): the `hits` children that were hit below the new top
-                    if (__builtin_expect(__ballot(sp + 3 >= ldsCap) == 0, 1)) {
+                    uint32_t e[MIPT_NODE_WIDTH];
+                    #pragma unroll
+                    for (int k = 0; k < MIPT_NODE_WIDTH; k++)
+                        e[k] = box_entry<MODE>(br, word(3 * k), word(3 * k + 1), word(3 * k + 2), tcull, word(3 * MIPT_NODE_WIDTH + k), slotMask, hits);
+                    // a network of compare-exchanges sorts the entries, largest (farthest) first
+#if MIPT_NODE_WIDTH == 4
+                    order_pair(e[0], e[1]); order_pair(e[2], e[3]);
+                    order_pair(e[0], e[2]); order_pair(e[1], e[3]);
+                    order_pair(e[1], e[2]);
+#else
+                    order_pair(e[0], e[1]); order_pair(e[2], e[3]); order_pair(e[4], e[5]); order_pair(e[6], e[7]);
+                    order_pair(e[0], e[2]); order_pair(e[1], e[3]); order_pair(e[4], e[6]); order_pair(e[5], e[7]);
+                    order_pair(e[1], e[2]); order_pair(e[5], e[6]);
+                    order_pair(e[0], e[4]); order_pair(e[1], e[5]); order_pair(e[2], e[6]); order_pair(e[3], e[7]);
+                    order_pair(e[2], e[4]); order_pair(e[3], e[5]);
+                    order_pair(e[1], e[2]); order_pair(e[3], e[4]); order_pair(e[5], e[6]);
+#endif
+                    // all of them go on the stack as they stand (as many spare entries): the `hits` children that were hit below the new top
+                    if (__builtin_expect(__ballot(sp + MIPT_NODE_WIDTH - 1 >= ldsCap) == 0, 1)) {
                         uint32_t* st = stack + sp * WAVE;
-                        st[0] = e0; st[WAVE] = e1; st[2 * WAVE] = e2; st[3 * WAVE] = e3;
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_WIDTH; k++) st[k * WAVE] = e[k];
                     } else {
-                        stack_store(stack, spill, ldsCap, sp, e0); stack_store(stack, spill, ldsCap, sp + 1, e1);
-                        stack_store(stack, spill, ldsCap, sp + 2, e2); stack_store(stack, spill, ldsCap, sp + 3, e3);
+                        #pragma unroll
+                        for (int k = 0; k < MIPT_NODE_WIDTH; k++) stack_store(stack, spill, ldsCap, sp + k, e[k]);
                     }
                     sp += hits;
                     cur = pop();
@@ -516,8 +537,9 @@ static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount,
     t.waves = wavesEnv;
     t.cacheSlots = (int)(numNodeSlots < cacheEnv ? numNodeSlots : cacheEnv);
     const size_t perWave = (size_t)S.stackLds * WAVE * sizeof(uint32_t);
-    t.smem = (size_t)t.cacheSlots * 64 + perWave * (size_t)t.waves + (size_t)extra;
-    while (t.smem > 160 * 1024 && t.cacheSlots > 0) { t.cacheSlots /= 2; t.smem = (size_t)t.cacheSlots * 64 + perWave * (size_t)t.waves + (size_t)extra; }
+    const size_t slotBytes = 16 * MIPT_NODE_U4;
+    t.smem = (size_t)t.cacheSlots * slotBytes + perWave * (size_t)t.waves + (size_t)extra;
+    while (t.smem > 160 * 1024 && t.cacheSlots > 0) { t.cacheSlots /= 2; t.smem = (size_t)t.cacheSlots * slotBytes + perWave * (size_t)t.waves + (size_t)extra; }
     int perCU = t.smem ? (int)((160 * 1024) / t.smem) : 32;
     if (perCU * t.waves > 32) perCU = 32 / t.waves;
     if (perCU < 1) perCU = 1;

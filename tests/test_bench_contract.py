@@ -36,7 +36,7 @@ def test_bench_line_numbers_hang_together():
     assert d["value"] == pytest.approx(c["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
     assert c["reference_rays_per_frame"] == pytest.approx(c["rays_per_frame"] + c["shadow_rays_not_traversed_per_frame"])
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
-    assert 2.0 <= r["box_tests_per_node_visit"] <= 4.0
+    assert 2.0 <= r["box_tests_per_node_visit"] <= c["bvh_node_width"]
     # the HBM fraction is the measured fabric-side traffic of a launch over its duration, against the peak
     assert r["hbm_frac"] == pytest.approx(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["hbm_peak_gbs"], rel=1e-6)
     assert 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # the tree is served from the caches

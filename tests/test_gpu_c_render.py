@@ -340,5 +340,5 @@ def test_box_tests_are_counted_on_request(gpu, atrium_small):
     img1, ids1, st1 = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=2, count_box_tests=1))
     assert st0.closest_box_tests == 0
     assert st1.closest_node_visits == st0.closest_node_visits > 0
-    assert 2 * st1.closest_node_visits <= st1.closest_box_tests <= 4 * st1.closest_node_visits
+    assert 2 * st1.closest_node_visits <= st1.closest_box_tests <= sc.info().node_width * st1.closest_node_visits
     assert np.array_equal(img0, img1) and np.array_equal(ids0, ids1)
