@@ -311,16 +311,17 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     for (int a = 0; a < 3; a++) { D.qmin[a] = s->bvh.qmin[a]; D.qcell[a] = s->bvh.qcell[a]; }
     D.rootCode = s->bvh.rootCode;
     // depth-first walk of a tree whose nodes push up to (width - 1) siblings per level
-    D.stackDepth = (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2 + MIPT_NODE_WIDTH;     // + spare entries a node step may scribble on
+    // (two bottom rows that mark the end of the stack, and spare rows a node step may scribble on)
+    D.stackDepth = 2 + (MIPT_NODE_WIDTH - 1) * s->bvh.maxDepth + 2 + MIPT_NODE_WIDTH;
     D.stackLds = D.stackDepth < MIPT_STACK_LDS_MAX ? D.stackDepth : MIPT_STACK_LDS_MAX;
-    if (const char* e = getenv("MIPT_STACK_LDS")) {          // test hook: a small LDS part sends the stack through its global-memory slice
+    if (const char* e = getenv("MIPT_STACK_LDS")) {          // test hook: a small LDS part (this many rows above the two bottom rows) sends the stack through its global-memory slice
         int v = atoi(e);
-        if (v >= 1 && v < D.stackLds) D.stackLds = v;
+        if (v >= 1 && v + 2 < D.stackLds) D.stackLds = v + 2;
     }
     D.numTris = (int32_t)n; D.numMats = s->numMats; D.numNodeSlots = s->bvh.numNodeSlots;
     D.leafBase = (uint32_t)s->bvh.numNodeSlots;
     {
-        uint64_t codes = (uint64_t)s->bvh.numNodeSlots + (uint64_t)s->bvh.numLeafSlots;      // child codes are 0 .. codes - 1
+        uint64_t codes = (uint64_t)s->bvh.numNodeSlots + (uint64_t)s->bvh.numLeafSlots + 1;      // child codes are 0 .. codes - 2, codes - 1 marks the end of a stack
         if (codes >= (1ull << 30)) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too large"); }
         uint32_t m = 1;
         while (m < codes) m <<= 1;
@@ -694,12 +695,9 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
             stats->closest_rays -= (uint64_t)((int64_t)P - owned);
         }
 #ifdef MIPT_TRACE_PROFILE
-        fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu\n",
-                h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6]);
-#endif
-#ifdef MIPT_TRACE_HIST
-        fprintf(stderr, "trace histogram (closest): nodeVisits %llu | of these at node slot < 256: %llu  < 512: %llu  < 1024: %llu  < 2048: %llu  < 4096: %llu | with stack depth >= 6: %llu  >= 9: %llu  >= 12: %llu\n",
-                h[ST_CLOSEST_NODES], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7]);
+        fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu slowNodeSteps %llu | lanes per node step %.1f per triangle step %.1f\n",
+                h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7],
+                h[ST_PROF + 1] ? (double)h[ST_CLOSEST_NODES] / (double)h[ST_PROF + 1] : 0.0, h[ST_PROF + 2] ? (double)h[ST_CLOSEST_TRIS] / (double)h[ST_PROF + 2] : 0.0);
 #endif
         stats->node_visits = h[ST_CLOSEST_NODES] + h[ST_SHADOW_NODES];
         stats->triangle_tests = h[ST_CLOSEST_TRIS] + h[ST_SHADOW_TRIS];

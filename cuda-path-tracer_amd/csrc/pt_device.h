@@ -116,6 +116,26 @@ __device__ __forceinline__ bool ray_triangle(F3 o, F3 d, F3 v0, F3 e1, F3 e2, fl
     return accept;
 }
 
+// The same test with the division done on every lane, accepted or not (straight-line code for the
+// traversal; t, u, v of a rejected triangle are not used).  Same operations in the same order.
+__device__ __forceinline__ bool ray_triangle_all(F3 o, F3 d, F3 v0, F3 e1, F3 e2, float eps, float& t, float& u, float& v)
+{
+    F3 p = f3cross(d, e2);
+    float det = f3dot(e1, p);
+    F3 s = f3sub(o, v0);
+    float uu = f3dot(s, p);
+    F3 q = f3cross(s, e1);
+    float vv = f3dot(d, q);
+    float tt = f3dot(e2, q);
+    bool pos = det >= eps;
+    bool neg = det <= -eps;
+    bool rejP = (uu < 0.0f) | (uu > det) | (vv < 0.0f) | ((uu + vv) > det) | (tt < 0.0f);
+    bool rejN = (uu > 0.0f) | (uu < det) | (vv > 0.0f) | ((uu + vv) < det) | (tt > 0.0f);
+    float inv = 1.0f / det;
+    t = tt * inv; u = uu * inv; v = vv * inv;
+    return (pos & !rejP) | (!pos & neg & !rejN);
+}
+
 // ---------------------------------------------------------------------------------------
 // Ray prepared for the box test on the 16-bit grid: with box coordinate = qmin + q * qcell the
 // slab distance (coordinate - origin) / direction becomes q * (qcell / d) + (qmin - o) / d, one

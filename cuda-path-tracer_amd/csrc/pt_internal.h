@@ -28,7 +28,7 @@
 #define MIPT_NODE_WIDTH 4      // children per node slot: 4 (64-byte slots) or 8 (128-byte slots: words 3k .. 3k+2 = box of child k, words 24 .. 31 = child codes)
 #endif
 #define MIPT_NODE_U4 MIPT_NODE_WIDTH   // uint4 per node slot
-#define MIPT_STACK_LDS_MAX 16   // stack entries (4 bytes) per lane kept in LDS (4 KiB per wave); deeper entries, which one node visit in ten thousand needs, go to the spill slice
+#define MIPT_STACK_LDS_MAX 16   // stack rows (4 bytes per lane) kept in LDS (4 KiB per wave), the two bottom rows that mark the end of every lane's stack included; deeper rows, which one node step in two hundred needs, go to the spill slice
 #define MIPT_SHADE_F4 8
 // A queue in blocks: entries [b << MIPT_QBLOCK_SHIFT, (b << MIPT_QBLOCK_SHIFT) + blockCount[b]) of every block b are valid
 #define MIPT_QBLOCK_SHIFT 10
@@ -59,9 +59,9 @@ struct DevScene {
     float              qcell[3];
     uint32_t           rootCode;   // MIPT_NO_NODE for an empty scene
     uint32_t           leafBase;   // child codes from here on are leaves (= number of node slots)
-    uint32_t           slotMask;   // 2^b - 1 with the smallest b that holds every child code; the bits above it carry the sort key in a stack entry
-    int32_t            stackDepth; // entries of the per-lane traversal stack the tree can need
-    int32_t            stackLds;   // of these, entries kept in LDS; the rest live in stackSpill
+    uint32_t           slotMask;   // 2^b - 1 with the smallest b that holds every child code and the code after the last one (leafBase + numTris, "finished"); the bits above it carry the sort key in a stack entry
+    int32_t            stackDepth; // rows of the per-lane traversal stack the tree can need, the two bottom rows that hold "finished" included
+    int32_t            stackLds;   // of these, rows kept in LDS (at least 3); the rest live in stackSpill
     uint32_t*          stackSpill; // (stackDepth - stackLds) * 64 entries per resident wave, or null
     int32_t            numTris;
     int32_t            numMats;
@@ -89,8 +89,8 @@ enum {
     ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
     ST_SHADOW_CULLED, // shadow rays that were not traced because the direct term they guard is zero
     ST_CLOSEST_BOXES, // child boxes present in the nodes the closest-hit queries visited (counted on request only)
-    ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel, 8 entries
-    ST_COUNT = 16
+    ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel
+    ST_COUNT = 32
 };
 
 // ---- BVH build result -------------------------------------------------------------------
