@@ -699,6 +699,10 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7],
                 h[ST_PROF + 1] ? (double)h[ST_CLOSEST_NODES] / (double)h[ST_PROF + 1] : 0.0, h[ST_PROF + 2] ? (double)h[ST_CLOSEST_TRIS] / (double)h[ST_PROF + 2] : 0.0);
 #endif
+#ifdef MIPT_TRACE_CLOCK
+        fprintf(stderr, "trace clock (closest, summed over waves): node phases %.4g cycles (%.3f), triangle phases %.4g (%.3f), all %.4g\n",
+                (double)h[ST_PROF + 8], (double)h[ST_PROF + 8] / (double)h[ST_PROF + 10], (double)h[ST_PROF + 9], (double)h[ST_PROF + 9] / (double)h[ST_PROF + 10], (double)h[ST_PROF + 10]);
+#endif
         stats->node_visits = h[ST_CLOSEST_NODES] + h[ST_SHADOW_NODES];
         stats->triangle_tests = h[ST_CLOSEST_TRIS] + h[ST_SHADOW_TRIS];
         stats->closest_node_visits = h[ST_CLOSEST_NODES]; stats->closest_triangle_tests = h[ST_CLOSEST_TRIS];

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #define WAVE 64
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // queue entries a wave of a shading kernel handles per reservation in its output queues
 #define SHADE_ITEMS 16
 
@@ -233,6 +234,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_PROFILE
     uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0, pSlow = 0;
 #endif
+#ifdef MIPT_TRACE_CLOCK
+    // shader-clock cycles this wave spends in node phases, in triangle phases and in the rest of a round
+    unsigned long long cNode = 0, cTri = 0, cAll = __builtin_readcyclecounter();
+#endif
 
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
     bool queueDry = false;
@@ -276,26 +281,39 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         }
     };
     auto node_step = [&](bool lds) {
-        // the node slot as words: 3k .. 3k+2 = box of child k, 12 .. 15 = child codes
-        uint4 q4[MIPT_NODE_U4];
-        if (cur < (uint32_t)cacheSlots) {       // the top of the tree is read from the workgroup's copy in LDS
-            const uint4* nd = smem4 + cur * MIPT_NODE_U4;
-            #pragma unroll
-            for (int k = 0; k < MIPT_NODE_U4; k++) q4[k] = nd[k];
-            // keeps the two kinds of load apart: merged into one flat load they would all go through the
-            // vector memory pipeline
-            #pragma unroll
-            for (int k = 0; k < MIPT_NODE_U4; k++) asm volatile("" : "+v"(q4[k].x));
-        } else {
-            const uint4* nd = nodes + (size_t)cur * MIPT_NODE_U4;
-            #pragma unroll
-            for (int k = 0; k < MIPT_NODE_U4; k++) q4[k] = nd[k];
-            #pragma unroll
-            for (int k = 0; k < MIPT_NODE_U4; k++) asm volatile("" : "+v"(q4[k].x));
-        }
         uint32_t upper, lower;
         rows_below(lds, upper, lower);
-        auto word = [&](int i) -> uint32_t { const uint4& v = q4[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
+        // The node slot as words: 3k .. 3k+2 = box of child k, 12 .. 15 = child codes.  The top of the tree is
+        // read from the workgroup's copy in LDS, the rest from memory, into the same registers: the lanes of
+        // either kind issue their four 16-byte loads under their own exec mask and the wave then waits once
+        // for both kinds.  (Written as two branches, each kind would wait for its own loads before the other
+        // kind issues; written as one load whose address decides, all lanes would go through the vector
+        // memory pipeline.)
+        u32x4 q0, q1, q2, q3;
+        {
+            const uint32_t ldsAddr = (uint32_t)(size_t)(smem4 + (size_t)cur * MIPT_NODE_U4);
+            const uint4* gaddr = nodes + (size_t)cur * MIPT_NODE_U4;
+            unsigned long long saved;
+            asm volatile(
+                "v_cmp_gt_u32_e32 vcc, %[cs], %[cur]\n\t"
+                "s_and_saveexec_b64 %[sv], vcc\n\t"
+                "ds_read_b128 %[q0], %[la]\n\t"
+                "ds_read_b128 %[q1], %[la] offset:16\n\t"
+                "ds_read_b128 %[q2], %[la] offset:32\n\t"
+                "ds_read_b128 %[q3], %[la] offset:48\n\t"
+                "s_andn2_b64 exec, %[sv], vcc\n\t"
+                "global_load_dwordx4 %[q0], %[ga], off\n\t"
+                "global_load_dwordx4 %[q1], %[ga], off offset:16\n\t"
+                "global_load_dwordx4 %[q2], %[ga], off offset:32\n\t"
+                "global_load_dwordx4 %[q3], %[ga], off offset:48\n\t"
+                "s_mov_b64 exec, %[sv]\n\t"
+                "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [sv] "=&s"(saved)
+                : [cs] "s"((uint32_t)cacheSlots), [cur] "v"(cur), [la] "v"(ldsAddr), [ga] "v"(gaddr)
+                : "vcc", "memory");
+        }
+        const u32x4 q4[MIPT_NODE_U4] = { q0, q1, q2, q3 };
+        auto word = [&](int i) -> uint32_t { const u32x4& v = q4[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
         nodeCount++;
         if (COUNT_BOXES) {
             #pragma unroll
@@ -441,10 +459,24 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         };
         // the triangle phase follows the node phase in the same round
         if (nodeMask != 0 && __popcll(triMask) < triVote) {
+#ifdef MIPT_TRACE_CLOCK
+            unsigned long long c0 = __builtin_readcyclecounter();
+#endif
             nodePhase();
+#ifdef MIPT_TRACE_CLOCK
+            cNode += __builtin_readcyclecounter() - c0;
+#endif
             triMask = __ballot(at_leaf(cur)); nodeMask = __ballot(at_node(cur));
         }
-        if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) triPhase();
+        if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) {
+#ifdef MIPT_TRACE_CLOCK
+            unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+            triPhase();
+#ifdef MIPT_TRACE_CLOCK
+            cTri += __builtin_readcyclecounter() - c0;
+#endif
+        }
 #ifdef MIPT_TRACE_PROFILE
         { unsigned long long fm = __ballot(cur == LANE_FINISHED); if (fm) { pFinish++; pFinishLanes += __popcll(fm); } }
 #endif
@@ -460,6 +492,11 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         atomicAdd(&stats[ST_PROF + 2], (unsigned long long)pTriIters); atomicAdd(&stats[ST_PROF + 3], (unsigned long long)pNodePhases);
         atomicAdd(&stats[ST_PROF + 4], (unsigned long long)pRefills); atomicAdd(&stats[ST_PROF + 5], (unsigned long long)pFinish);
         atomicAdd(&stats[ST_PROF + 6], (unsigned long long)pFinishLanes); atomicAdd(&stats[ST_PROF + 7], (unsigned long long)pSlow);
+    }
+#endif
+#ifdef MIPT_TRACE_CLOCK
+    if (lane == 0 && MODE == 0) {
+        atomicAdd(&stats[ST_PROF + 8], cNode); atomicAdd(&stats[ST_PROF + 9], cTri); atomicAdd(&stats[ST_PROF + 10], __builtin_readcyclecounter() - cAll);
     }
 #endif
     if (COUNT_BOXES) { unsigned long long bs = wave_sum_u32(boxCount); if (lane == 0 && bs) atomicAdd(&stats[ST_CLOSEST_BOXES], bs); }
