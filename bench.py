@@ -46,6 +46,7 @@ def cpu_baseline(scene, cam, params, budget_s=15.0):
     import oracle_binding as ob
     osc = ob.OracleScene(scene.desc)
     w, h = cam.image_size
+    # the GPU box gives a job 16 host cores of a much larger machine (os.cpu_count() reports the machine)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     # calibrate on a few rows, then size the sample to the time budget
     probe_step = max(1, h // 4)
@@ -58,7 +59,7 @@ def cpu_baseline(scene, cam, params, budget_s=15.0):
     rows_done = len(range(step // 2, h, step))
     rays = st.closest_rays + st.shadow_rays
     out = {
-        "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": st.threads, "kind": "port",
+        "value": rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": st.threads, "host_cpus": os.cpu_count(), "kind": "port",
         "sample": f"{rows_done} of {h} image rows (every {step}th), {rays} rays in {st.seconds:.1f} s, octree search, OpenMP",
     }
     # the reference's octree (Mesh.cpp:88-186) drops triangles that lie on a face of a re-fitted box: the search
@@ -76,16 +77,32 @@ def cpu_baseline(scene, cam, params, budget_s=15.0):
     return out
 
 
-def measured_traffic(workload):
-    """HBM-side bytes per launch of the closest-hit kernel from the committed counter run
-    (profiles/traffic.json, written by profiles/pmc_report.py from separate FETCH_SIZE and
-    WRITE_SIZE passes of this same command); None when there is no entry for the workload."""
+def kernel_source_hash():
+    """SHA-1 over the HIP sources the kernels are built from, in a fixed order: counter measurements are
+    only quoted for the code they were taken on (profiles/pmc_passes.sh stores the same hash)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "cuda-path-tracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(workload, kernel="k_trace<0>"):
+    """Fabric-side bytes per launch of one kernel from the committed counter run (profiles/traffic.json,
+    written by profiles/pmc_report.py from separate FETCH_SIZE and WRITE_SIZE passes of this same
+    command).  None when there is no entry for the workload and kernel, or when the entry was measured
+    on other kernel sources than the ones in the tree."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        e = t.get(workload)
-        return float(e["bytes_per_launch"]) if e else None
-    except (OSError, ValueError, KeyError):
+        e = t.get(workload, {}).get(kernel)
+        if not e or e.get("source_sha1") != kernel_source_hash():
+            return None
+        return float(e["bytes_per_launch"])
+    except (OSError, ValueError, KeyError, AttributeError):
         return None
 
 
@@ -116,8 +133,13 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)              # before the communicator is created: it binds to the current device
-    if world > 1:
+    # MIPT_BENCH_FORCE_PG=1: a one-rank run also creates its process group and sends its accumulator through the
+    # collective, so that the RCCL path (communicator bound to the device, collective stream -> library stream) is
+    # exercised on a single GPU
+    use_pg = world > 1 or os.environ.get("MIPT_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     device.init(local_rank)
     coll = "cuda" if backend == "nccl" else "cpu"      # where tensors handed to collectives live
@@ -138,7 +160,7 @@ def main():
 
     # tile shards: every rank traces, accumulates and finalizes its own tiles and the final images are added
     # (disjoint pixels: exact); sample shards: the unclamped sums are added and rank 0 finalizes
-    own_tiles = world > 1 and args.shard == "tiles"
+    own_tiles = (world > 1 or os.environ.get("MIPT_BENCH_FORCE_PG") == "1") and args.shard == "tiles"
     shard = sharding.shard_fields(rank, world, samples, args.shard, own_pixels_only=own_tiles)
     # MIPT_BENCH_AS_SHARD=r/N (single process only): time the work of rank r of an N-rank run alone, to see how
     # the per-rank frame time falls with N where only one GPU is at hand
@@ -154,13 +176,13 @@ def main():
     out = torch.zeros(npx * 3, dtype=torch.float32, device="cuda")
 
     def reduce(t):
-        if world > 1 and coll == "cpu":
+        if use_pg and coll == "cpu":
             host_sum = t.cpu()
-            sharding.reduce_to_rank0(host_sum, dist, world)
+            sharding.reduce_to_rank0(host_sum, dist, world, force=use_pg)
             if rank == 0:
                 t.copy_(host_sum)
         else:
-            sharding.reduce_to_rank0(t, dist, world)
+            sharding.reduce_to_rank0(t, dist, world, force=use_pg)
 
     def step():
         st = frame.accumulate(accum.data_ptr())
@@ -174,7 +196,7 @@ def main():
         return st
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -192,6 +214,7 @@ def main():
     frame.set_params(cam, params)
     counted = frame.accumulate(accum.data_ptr())
     boxes_per_visit = counted.closest_box_tests / max(counted.closest_node_visits, 1)
+    shadow_boxes_per_visit = counted.shadow_box_tests / max(counted.node_visits - counted.closest_node_visits, 1)
 
     tot = torch.tensor([
         float(sum(s.closest_rays + s.shadow_rays for s in stats)),
@@ -200,9 +223,12 @@ def main():
         float(sum(s.triangle_tests for s in stats)), float(sum(s.node_visits for s in stats)),
         float(sum(s.shadow_ms for s in stats)), float(sum(s.closest_rays for s in stats)),
         float(sum(s.shade_ms for s in stats)), float(sum(s.shadow_rays_culled for s in stats)),
+        float(sum(s.shade_bounce_ms for s in stats)), float(sum(s.shade_bounce_launches for s in stats)),
+        float(sum(s.shaded_hits for s in stats)), float(sum(s.bounce_rays_written for s in stats)),
+        float(sum(s.shadow_launches for s in stats)), float(sum(s.shadow_rays for s in stats)),
     ], dtype=torch.float64, device=coll)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # rays and counters add over ranks; kernel time is per-rank wall time of rank 0's kernels
         sums = tot.clone()
@@ -228,6 +254,26 @@ def main():
         achieved_tf = flops / closest_s / 1e12 if closest_s > 0 else 0.0
         launches = max(tot[4].item(), 1.0)
         traffic = measured_traffic(args.workload)
+        valu_frac = achieved_tf / FP32_VECTOR_PEAK_TFLOPS
+        hbm_frac = (traffic / (closest_s / launches) / 1e9) / HBM_PEAK_GBS if traffic and closest_s > 0 else None
+        # any-hit traversal: the same units of work as the closest-hit kernel
+        shadow_s = tot[7].item() / 1e3
+        sh_tests, sh_visits = tot[5].item() - tot[1].item(), tot[6].item() - tot[2].item()
+        sh_flops = FLOP_PER_TRI_TEST * sh_tests + FLOP_PER_BOX_TEST * shadow_boxes_per_visit * sh_visits
+        sh_tf = sh_flops / shadow_s / 1e12 if shadow_s > 0 else 0.0
+        sh_launches = max(tot[15].item(), 1.0)
+        sh_traffic = measured_traffic(args.workload, "k_trace<1>")
+        # bounce shading: per shaded hit one 16-byte hit record, one 128-byte shading record and one 4-byte texel are
+        # read and a 16-byte path state is written; per shadow ray and per ray of the next depth 32 bytes are written;
+        # a ray that missed costs its hit record and a zero path state
+        bounce_s = tot[11].item() / 1e3
+        b_launches = max(tot[12].item(), 1.0)
+        hits, next_rays = tot[13].item(), tot[14].item()
+        bounce_in = tot[8].item() - args.steps * npx if world == 1 else None          # rays of depth 1..3 (one rank: all but the primary rays)
+        shadow_bounce = tot[16].item()                     # includes the primary level's shadow rays (at most one per pixel)
+        b_bytes = hits * (16 + 128 + 4 + 16) + 32 * shadow_bounce + 32 * next_rays + ((bounce_in - hits) * 32 if bounce_in else 0)
+        b_gbs = b_bytes / bounce_s / 1e9 if bounce_s > 0 else 0.0
+        b_traffic = measured_traffic(args.workload, "k_shade_bounce")
         result = {
             "metric": "Mrays/s (1 & 8 GPU) + render time, Crytek Sponza GI 128 spp 1080p",
             "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -248,9 +294,10 @@ def main():
                 "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "image_sha1": image_sha1, "samples_per_pass": int(s0.chunk_samples),
             },
             "roofline": {
-                "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu",
+                # the larger of the two shares names the bound: FP32 vector peak or HBM peak
+                "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu" if (hbm_frac or 0.0) <= valu_frac else "hbm",
                 "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                "frac": valu_frac, "traffic": traffic,
                 "traffic_unit": "bytes per launch, fabric side of L2 (profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": bytes_ / launches,
                 "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
@@ -261,18 +308,34 @@ def main():
                 # served by LDS, L1 and L2: this is a request rate, not memory traffic
                 "requested_gbs": bytes_ / closest_s / 1e9 if closest_s > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
                 # share of the HBM peak that the measured fabric-side traffic of a launch amounts to
-                "hbm_frac": (traffic / (closest_s / launches) / 1e9) / HBM_PEAK_GBS if traffic and closest_s > 0 else None,
+                "hbm_frac": hbm_frac,
                 "box_tests_per_node_visit": boxes_per_visit,
                 "closest_ms_per_step": [round(s.closest_ms, 3) for s in stats], "shadow_ms_per_step": [round(s.shadow_ms, 3) for s in stats],
                 "kernel_time_share": {"closest": tot[3].item() / (1e3 * elapsed), "shadow": tot[7].item() / (1e3 * elapsed),
                                       "shading": tot[9].item() / (1e3 * elapsed)},
             },
         }
+        result["roofline_kernels"] = [
+            {"kernel": "k_trace<1> (any-hit BVH traversal of the shadow rays)", "bound": "valu", "achieved": sh_tf,
+             "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sh_tf / FP32_VECTOR_PEAK_TFLOPS,
+             "traffic": sh_traffic, "avg_launch_ms": 1e3 * shadow_s / sh_launches, "launches": int(sh_launches),
+             "ms_per_step": 1e3 * shadow_s / args.steps, "box_tests_per_node_visit": shadow_boxes_per_visit,
+             "triangle_tests_per_s": sh_tests / shadow_s if shadow_s > 0 else 0.0, "node_visits_per_s": sh_visits / shadow_s if shadow_s > 0 else 0.0,
+             "hbm_frac": (sh_traffic / (shadow_s / sh_launches) / 1e9) / HBM_PEAK_GBS if sh_traffic and shadow_s > 0 else None},
+            {"kernel": "k_shade_bounce (surface, light and next sample at depth 1..3)", "bound": "hbm", "achieved": b_gbs,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_gbs / HBM_PEAK_GBS, "traffic": b_traffic,
+             "algorithmic_bytes_per_launch": b_bytes / b_launches, "avg_launch_ms": 1e3 * bounce_s / b_launches, "launches": int(b_launches),
+             "ms_per_step": 1e3 * bounce_s / args.steps, "shaded_hits_per_s": hits / bounce_s if bounce_s > 0 else 0.0,
+             # measured fabric-side traffic (Infinity Cache hits included) over the launch time, against the HBM peak
+             "traffic_frac": (b_traffic / (bounce_s / b_launches) / 1e9) / HBM_PEAK_GBS if b_traffic and bounce_s > 0 else None},
+        ]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, cam, params)
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / max(result["cpu_baseline"]["value"], 1e-9)
+        if use_pg:
+            result["config"]["process_group"] = f"{backend}x{world}"
         print(json.dumps(result))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -558,7 +558,7 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
     f->numCounters = CTR_FIXED + CTR_PER_PASS * passes;
     FRTRY(hipMalloc(&f->counters, 4 * (size_t)f->numCounters));
     FRTRY(hipMalloc(&f->stats, 8 * ST_COUNT));
-    f->events.resize(2 + 2 * (size_t)(2 + passes * 6));
+    f->events.resize(2 + 2 * (size_t)(2 + passes * 9));
     for (auto& e : f->events) { e = nullptr; FRTRY(hipEventCreate(&e)); }
     *out = f;
     return MIPT_OK;
@@ -594,7 +594,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     const int32_t P = f->P;
     const int64_t total = P;
     size_t ev = 0;
-    std::vector<std::pair<size_t, int>> spans;    // (first event index, kind 0 closest / 1 shadow)
+    std::vector<std::pair<size_t, int>> spans;    // (first event index, kind 0 closest / 1 shadow / 2 bounce shading)
     auto spanBegin = [&](int kind) { spans.push_back({ ev, kind }); (void)hipEventRecord(f->events[ev++], st); };
     auto spanEnd = [&]() { (void)hipEventRecord(f->events[ev++], st); };
 
@@ -613,7 +613,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     spanEnd();
     launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, f->stats, st);
     spanBegin(1);
-    launch_shadow(S, f->primShadowQ, f->counters + 2, nullptr, P, f->counters + 3, f->pixState, f->pathState, f->slotCap, R.eps, f->stats, g_numCUs, st);
+    launch_shadow(S, f->primShadowQ, f->counters + 2, nullptr, P, f->counters + 3, f->pixState, f->pathState, f->slotCap, R.eps, f->stats, g_numCUs, st, R.countBoxTests != 0);
     spanEnd();
 
     int32_t nAct = 0;
@@ -651,10 +651,12 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     spanBegin(0);
                     launch_closest(S, cur, inCount, (int32_t)slots, Lc + 0, f->hit, R.eps, f->stats, g_numCUs, st, true, R.countBoxTests != 0);
                     spanEnd();
+                    spanBegin(2);
                     launch_shade_bounce(S, R, cur, f->hit, inCount, (int32_t)slots, level, f->actPix, nAct, n0, f->pathState, slots,
                                         f->shadowQ, f->shadowBlocks, nxt, Lc + 1, f->stats, st);
+                    spanEnd();
                     spanBegin(1);
-                    launch_shadow(S, f->shadowQ, inCount, f->shadowBlocks, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st);
+                    launch_shadow(S, f->shadowQ, inCount, f->shadowBlocks, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st, R.countBoxTests != 0);
                     spanEnd();
                 }
                 launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);
@@ -682,6 +684,7 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         unsigned long long h[ST_COUNT];
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED]; stats->closest_box_tests = h[ST_CLOSEST_BOXES];
+        stats->shadow_box_tests = h[ST_SHADOW_BOXES]; stats->shaded_hits = h[ST_SHADE_HITS]; stats->bounce_rays_written = h[ST_SHADE_NEXT];
         if (R.ownPixelsOnly) {
             // the stand-in rays of pixels that belong to other shards are no rays of the image: not counted
             int64_t owned = 0;
@@ -711,7 +714,8 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
             float ms = 0;
             if (hipEventElapsedTime(&ms, f->events[sp.first], f->events[sp.first + 1]) == hipSuccess) {
                 if (sp.second == 0) { stats->closest_ms += ms; stats->closest_launches++; }
-                else { stats->shadow_ms += ms; stats->shadow_launches++; }
+                else if (sp.second == 1) { stats->shadow_ms += ms; stats->shadow_launches++; }
+                else { stats->shade_bounce_ms += ms; stats->shade_bounce_launches++; }
             }
         }
         float tot = 0;

@@ -162,6 +162,8 @@ __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
 
 // Slab test against a box given as three node words; tnear, tfar = entry and exit distance.  Conservative by
 // construction of the node boxes, never exact.
+// CULL: the exit distance is also cut at tcull, the distance beyond which a box cannot matter (closest hit).
+template <bool CULL>
 __device__ __forceinline__ bool box_test(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, float& tnear, float& tfar)
 {
     uint32_t px = __builtin_amdgcn_alignbit(wx, wx, r.sx), py = __builtin_amdgcn_alignbit(wy, wy, r.sy), pz = __builtin_amdgcn_alignbit(wz, wz, r.sz);
@@ -169,7 +171,7 @@ __device__ __forceinline__ bool box_test(const BoxRay& r, uint32_t wx, uint32_t 
     float y0 = __builtin_fmaf((float)(py & 0xffffu), r.iy, r.ny), y1 = __builtin_fmaf((float)(py >> 16), r.iy, r.ny);
     float z0 = __builtin_fmaf((float)(pz & 0xffffu), r.iz, r.nz), z1 = __builtin_fmaf((float)(pz >> 16), r.iz, r.nz);
     float tmin = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
-    float tmax = fminf(fminf(x1, y1), fminf(z1, tcull));
+    float tmax = CULL ? fminf(fminf(x1, y1), fminf(z1, tcull)) : fminf(fminf(x1, y1), z1);
     tnear = tmin; tfar = tmax;
     return tmin <= tmax;
 }

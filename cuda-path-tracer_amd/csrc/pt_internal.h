@@ -89,7 +89,10 @@ enum {
     ST_CLOSEST_RAYS = 0, ST_SHADOW_RAYS, ST_CLOSEST_NODES, ST_CLOSEST_TRIS, ST_SHADOW_NODES, ST_SHADOW_TRIS,
     ST_SHADOW_CULLED, // shadow rays that were not traced because the direct term they guard is zero
     ST_CLOSEST_BOXES, // child boxes present in the nodes the closest-hit queries visited (counted on request only)
-    ST_PROF = 8,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel
+    ST_SHADOW_BOXES,  // the same for the any-hit queries
+    ST_SHADE_HITS,    // hits shaded by k_shade_bounce
+    ST_SHADE_NEXT,    // rays k_shade_bounce wrote to the queue of the next depth
+    ST_PROF = 11,      // with -DMIPT_TRACE_PROFILE: wave-level step counts of the closest-hit kernel
     ST_COUNT = 32
 };
 
@@ -128,7 +131,7 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
 // any-hit over q[0 .. *d_count): clears the direct term of the slot the ray belongs to when occluded
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
-                   unsigned long long* d_stats, int numCUs, hipStream_t s);
+                   unsigned long long* d_stats, int numCUs, hipStream_t s, bool countBoxes = false);
 // any-hit for caller-supplied rays: out[i] = 1 if occluded
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s);

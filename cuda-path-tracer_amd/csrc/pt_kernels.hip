@@ -14,6 +14,9 @@
 // A path slot is (first-bounce sample s of this pass, active pixel a): slot = s * nAct + a.
 #include "pt_device.h"
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
+#include <stdio.h>
 
 #define WAVE 64
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -153,10 +156,15 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // result, PathTracer.cu:291).  MODE 1 clears the direct term of the slot the shadow ray belongs
 // to; MODE 2 writes flags[i].
 #define TRACE_CHUNK 256
+#define TRACE_CHUNK_SHADOW 512
 #define TRACE_WAVES 12            // waves per workgroup
 #define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
 #define TRACE_TRI_VOTE 16
 #define TRACE_NODE_DROP 28
+#define TRACE_REFILL_MIN 1     // idle lanes a wave waits for before it hands out new rays
+#define TRACE_TRI_VOTE_SHADOW 16
+#define TRACE_NODE_DROP_SHADOW 28
+#define TRACE_TRI_STAY_SHADOW 3
 #define TRACE_TRI_STAY 3      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
 static_assert(MIPT_NODE_WIDTH == 4, "the node step is written for four-wide nodes");
 
@@ -187,10 +195,11 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32
 #define ENTRY_MISS 0u
 #define CULL_NONE  0x7fffffffu     // no hit yet: every entry passes
 template <int MODE>
-__device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t keyMask)
+__device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t keyMask, int& hits)
 {
     float t0, t1;
-    bool h = box_test(r, wx, wy, wz, tcull, t0, t1);
+    bool h = box_test<MODE == 0>(r, wx, wy, wz, tcull, t0, t1);
+    hits += h;
     uint32_t key = (MODE != 0) ? 0x7f7fffffu - __float_as_uint(t1 - t0) : __float_as_uint(t0);
     uint32_t e = code | (key & keyMask);      // codes of children that exist are below slotMask; a child that does not exist is always missed
     return h ? e : ENTRY_MISS;
@@ -206,8 +215,10 @@ template <int MODE, bool BLOCKS, bool COUNT_BOXES = false>
 __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const int32_t* __restrict__ d_count,
                                                 const int32_t* __restrict__ blockCount, int32_t* head, float4* __restrict__ hit, float4* pixState0,
                                                 float4* pathState, int64_t slotsPerLevel, uint8_t* flags,
-                                                float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagInHit, int cacheSlots)
+                                                float eps, unsigned long long* stats, int triVote, int chunk, int nodeDrop, int triStay, int tagAndRefill, int cacheSlots)
 {
+    const int tagInHit = tagAndRefill & 1, refillMin = tagAndRefill >> 8;      // lanes are handed new rays once this many of them are idle
+
     // LDS of the workgroup: the first cacheSlots node slots of the tree (its top levels, where more than
     // half of all node visits go), then one stack area per wave.  The waves of a workgroup share the
     // node copy and nothing else: after the copy is made they never meet again.
@@ -231,6 +242,9 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     auto at_node = [&](uint32_t c) { return c < leafBase; };
     auto at_leaf = [&](uint32_t c) { return c - leafBase < numLeaf; };
     uint32_t nodeCount = 0, triCount = 0, rayCount = 0, boxCount = 0;
+#ifdef MIPT_ABLATE_LOAD
+    uint32_t ablAcc = 0;
+#endif
 #ifdef MIPT_TRACE_PROFILE
     uint32_t pOuter = 0, pNodeIters = 0, pTriIters = 0, pNodePhases = 0, pRefills = 0, pFinish = 0, pFinishLanes = 0, pSlow = 0;
 #endif
@@ -281,8 +295,6 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         }
     };
     auto node_step = [&](bool lds) {
-        uint32_t upper, lower;
-        rows_below(lds, upper, lower);
         // The node slot as words: 3k .. 3k+2 = box of child k, 12 .. 15 = child codes.  The top of the tree is
         // read from the workgroup's copy in LDS, the rest from memory, into the same registers: the lanes of
         // either kind issue their four 16-byte loads under their own exec mask and the wave then waits once
@@ -290,6 +302,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         // kind issues; written as one load whose address decides, all lanes would go through the vector
         // memory pipeline.)
         u32x4 q0, q1, q2, q3;
+#ifdef MIPT_ABLATE_LOAD
+        // what three more 8-byte loads of the node's own cache line cost (lanes that read the node from memory only)
+        unsigned long long ablX0 = 0, ablX1 = 0, ablX2 = 0;
+#endif
         {
             const uint32_t ldsAddr = (uint32_t)(size_t)(smem4 + (size_t)cur * MIPT_NODE_U4);
             const uint4* gaddr = nodes + (size_t)cur * MIPT_NODE_U4;
@@ -306,12 +322,23 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                 "global_load_dwordx4 %[q1], %[ga], off offset:16\n\t"
                 "global_load_dwordx4 %[q2], %[ga], off offset:32\n\t"
                 "global_load_dwordx4 %[q3], %[ga], off offset:48\n\t"
+#ifdef MIPT_ABLATE_LOAD
+                "global_load_dwordx2 %[x0], %[ga], off offset:8\n\t"
+                "global_load_dwordx2 %[x1], %[ga], off offset:24\n\t"
+                "global_load_dwordx2 %[x2], %[ga], off offset:40\n\t"
+#endif
                 "s_mov_b64 exec, %[sv]\n\t"
                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
                 : [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [sv] "=&s"(saved)
+#ifdef MIPT_ABLATE_LOAD
+                  , [x0] "=&v"(ablX0), [x1] "=&v"(ablX1), [x2] "=&v"(ablX2)
+#endif
                 : [cs] "s"((uint32_t)cacheSlots), [cur] "v"(cur), [la] "v"(ldsAddr), [ga] "v"(gaddr)
                 : "vcc", "memory");
         }
+#ifdef MIPT_ABLATE_LOAD
+        ablAcc ^= (uint32_t)(ablX0 ^ ablX1 ^ ablX2);
+#endif
         const u32x4 q4[MIPT_NODE_U4] = { q0, q1, q2, q3 };
         auto word = [&](int i) -> uint32_t { const u32x4& v = q4[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
         nodeCount++;
@@ -321,26 +348,26 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         }
         // one entry per child, ENTRY_MISS where the ray misses the child's box
         uint32_t e[MIPT_NODE_WIDTH];
+        int hits = 0;
         #pragma unroll
         for (int k = 0; k < MIPT_NODE_WIDTH; k++)
-            e[k] = box_entry<MODE>(br, word(3 * k), word(3 * k + 1), word(3 * k + 2), tcull, word(3 * MIPT_NODE_WIDTH + k), keyMask);
+            e[k] = box_entry<MODE>(br, word(3 * k), word(3 * k + 1), word(3 * k + 2), tcull, word(3 * MIPT_NODE_WIDTH + k), keyMask, hits);
         // a network of compare-exchanges sorts the entries, largest (farthest) first
         order_pair(e[0], e[1]); order_pair(e[2], e[3]);
         order_pair(e[0], e[2]); order_pair(e[1], e[3]);
         order_pair(e[1], e[2]);
-        // the three farthest go on the stack as they stand; the rows of those that are the nearest hit or a miss stay above the new stack pointer
-        if (__builtin_expect(lds, 1)) { uint32_t* st = stack + sp * WAVE; st[0] = e[0]; st[WAVE] = e[1]; st[2 * WAVE] = e[2]; }
-        else { stack_store(stack, spill, ldsCap, sp, e[0]); stack_store(stack, spill, ldsCap, sp + 1, e[1]); stack_store(stack, spill, ldsCap, sp + 2, e[2]); }
-        // the nearest child that was hit = the last entry that is no miss; `more` = children hit beside it
-        uint32_t nearest = e[0];
-        int more = 0;
-        #pragma unroll
-        for (int k = 1; k < MIPT_NODE_WIDTH; k++) { bool h = e[k] != ENTRY_MISS; nearest = h ? e[k] : nearest; more += h; }
-        uint32_t old; int rows;
-        take(upper, lower, old, rows);
-        bool any = e[0] != ENTRY_MISS;
-        sp += any ? more : -rows;
-        cur = (any ? nearest : old) & slotMask;
+        // all four go on the stack as they stand: the children that were hit end up below the new stack pointer with
+        // the nearest one on top, the misses above it
+        if (__builtin_expect(lds, 1)) { uint32_t* st = stack + sp * WAVE; st[0] = e[0]; st[WAVE] = e[1]; st[2 * WAVE] = e[2]; st[3 * WAVE] = e[3]; }
+        else { stack_store(stack, spill, ldsCap, sp, e[0]); stack_store(stack, spill, ldsCap, sp + 1, e[1]); stack_store(stack, spill, ldsCap, sp + 2, e[2]); stack_store(stack, spill, ldsCap, sp + 3, e[3]); }
+        sp += hits;
+        // and the lane goes on with one of the two rows below the new stack pointer: the nearest child if one was hit
+        // (it cannot lie beyond the best hit: its box has just been tested against it), else an older entry
+        uint32_t upper, lower, next; int rows;
+        rows_below(lds, upper, lower);
+        take(upper, lower, next, rows);
+        sp -= rows;
+        cur = next & slotMask;
     };
     // the exact triangle test on one triangle of the lane's leaf
     auto tri_step = [&](bool lds) {
@@ -377,7 +404,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #endif
         // ---- hand rays to idle lanes
         unsigned long long idleMask = __ballot(cur == LANE_IDLE);
-        if (idleMask && !(queueDry && rangeNext >= rangeEnd)) {
+        if (idleMask && !(queueDry && rangeNext >= rangeEnd) && (__popcll(idleMask) >= refillMin || __ballot(cur < LANE_FINISHED) == 0)) {
             if (!BLOCKS) {
                 if (rangeNext >= rangeEnd) {
                     int b = 0;
@@ -436,7 +463,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                 pNodeIters++;
 #endif
                 if (at_node(cur)) {
-                    const bool lds = __ballot(sp + 2 >= ldsCap) == 0;
+                    const bool lds = __ballot(sp + 3 >= ldsCap) == 0;
 #ifdef MIPT_TRACE_PROFILE
                     pSlow += !lds;
 #endif
@@ -499,7 +526,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         atomicAdd(&stats[ST_PROF + 8], cNode); atomicAdd(&stats[ST_PROF + 9], cTri); atomicAdd(&stats[ST_PROF + 10], __builtin_readcyclecounter() - cAll);
     }
 #endif
-    if (COUNT_BOXES) { unsigned long long bs = wave_sum_u32(boxCount); if (lane == 0 && bs) atomicAdd(&stats[ST_CLOSEST_BOXES], bs); }
+#ifdef MIPT_ABLATE_LOAD
+    if (ablAcc == 0x12345u) stats[ST_PROF] = 1;      // keeps the extra loads alive
+#endif
+    if (COUNT_BOXES) { unsigned long long bs = wave_sum_u32(boxCount); if (lane == 0 && bs) atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_BOXES : ST_SHADOW_BOXES], bs); }
     if (lane == 0 && rs) {
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_RAYS : ST_SHADOW_RAYS], rs);
         atomicAdd(&stats[MODE == 0 ? ST_CLOSEST_NODES : ST_SHADOW_NODES], ns);
@@ -508,31 +538,53 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 }
 
 
-static int trace_tri_vote()
+// Phase thresholds, per kind of query (the any-hit kernel leaves a ray at its first accepted triangle and spends a
+// larger share of its steps on triangles): [0] closest hit, [1] any hit.  Environment switches for sweeps:
+// MIPT_TRACE_TRI_VOTE, _NODE_DROP, _TRI_STAY set both kinds, the same names with _SHADOW appended the any-hit kind alone.
+struct TraceThresholds { int triVote, nodeDrop, triStay; };
+static const TraceThresholds& trace_thresholds(bool anyHit)
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MIPT_TRACE_TRI_VOTE"); v = e ? atoi(e) : TRACE_TRI_VOTE; }
+    static TraceThresholds t[2];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto get = [](const char* name, bool shadow, int dflt) {
+            char buf[64];
+            snprintf(buf, sizeof(buf), "%s%s", name, shadow ? "_SHADOW" : "");
+            const char* e = getenv(buf);
+            if (!e && shadow) e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        for (int k = 0; k < 2; k++) {
+            t[k].triVote = get("MIPT_TRACE_TRI_VOTE", k == 1, k ? TRACE_TRI_VOTE_SHADOW : TRACE_TRI_VOTE);
+            t[k].nodeDrop = get("MIPT_TRACE_NODE_DROP", k == 1, k ? TRACE_NODE_DROP_SHADOW : TRACE_NODE_DROP);
+            int s = get("MIPT_TRACE_TRI_STAY", k == 1, k ? TRACE_TRI_STAY_SHADOW : TRACE_TRI_STAY);
+            t[k].triStay = s < 0 ? 0 : (s > 8 ? 8 : s);
+        }
+    });
+    return t[anyHit ? 1 : 0];
+}
+static int trace_tri_vote(bool anyHit = false) { return trace_thresholds(anyHit).triVote; }
+static int trace_node_drop(bool anyHit = false) { return trace_thresholds(anyHit).nodeDrop; }
+static int trace_tri_stay(bool anyHit = false) { return trace_thresholds(anyHit).triStay; }
+
+// rays an any-hit wave reserves at a time: a reservation in the shadow queue of a bounce level ends at its
+// block's last valid entry, so larger reservations lose fewer lanes to short tails (measured: 512 is 4 % faster
+// than 256 for the any-hit kernel and no different for the closest-hit kernel)
+static int trace_chunk_shadow()
+{
+    static const int v = [] { const char* e = getenv("MIPT_TRACE_CHUNK_SHADOW"); int x = e ? atoi(e) : TRACE_CHUNK_SHADOW; return x < 64 ? 64 : x; }();
     return v;
 }
 
-static int trace_node_drop()
+static int trace_refill_min()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MIPT_TRACE_NODE_DROP"); v = e ? atoi(e) : TRACE_NODE_DROP; }
-    return v;
-}
-
-static int trace_tri_stay()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MIPT_TRACE_TRI_STAY"); v = e ? atoi(e) : TRACE_TRI_STAY; if (v < 0) v = 0; if (v > 8) v = 8; }
+    static const int v = [] { const char* e = getenv("MIPT_TRACE_REFILL_MIN"); int x = e ? atoi(e) : TRACE_REFILL_MIN; return x < 1 ? 1 : (x > 64 ? 64 : x); }();
     return v;
 }
 
 static int trace_chunk()
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MIPT_TRACE_CHUNK"); v = e ? atoi(e) : TRACE_CHUNK; if (v < 64) v = 64; }
+    static const int v = [] { const char* e = getenv("MIPT_TRACE_CHUNK"); int x = e ? atoi(e) : TRACE_CHUNK; return x < 64 ? 64 : x; }();
     return v;
 }
 
@@ -549,12 +601,13 @@ static int env_int(const char* name, int dflt)
 
 static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount, int numCUs, int64_t numNodeSlots)
 {
-    static int wavesEnv = -1, cacheEnv = -1, extra = -1;
-    if (wavesEnv < 0) {
+    static int wavesEnv = TRACE_WAVES, cacheEnv = TRACE_CACHE_SLOTS, extra = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
         wavesEnv = env_int("MIPT_TRACE_WAVES", TRACE_WAVES); if (wavesEnv < 1) wavesEnv = 1; if (wavesEnv > 16) wavesEnv = 16;
         cacheEnv = env_int("MIPT_TRACE_CACHE", TRACE_CACHE_SLOTS); if (cacheEnv < 0) cacheEnv = 0;
         extra = env_int("MIPT_TRACE_LDS_EXTRA", 0);      // additional bytes per workgroup, to study occupancy
-    }
+    });
     TraceShape t;
     t.waves = wavesEnv;
     t.cacheSlots = (int)(numNodeSlots < cacheEnv ? numNodeSlots : cacheEnv);
@@ -566,21 +619,26 @@ static TraceShape trace_shape(const DevScene& S, bool closest, int32_t maxCount,
     if (perCU * t.waves > 32) perCU = 32 / t.waves;
     if (perCU < 1) perCU = 1;
     long long resident = (long long)numCUs * perCU;
-    long long neededWaves = ((long long)maxCount + trace_chunk() - 1) / trace_chunk();
+    const int chunk = closest ? trace_chunk() : trace_chunk_shadow();
+    long long neededWaves = ((long long)maxCount + chunk - 1) / chunk;
     long long needed = (neededWaves + t.waves - 1) / t.waves;
     long long g = needed < resident ? needed : resident;
     t.grid = (int)(g < 1 ? 1 : g);
     return t;
 }
 
-// The workgroups ask for more than 64 KiB of LDS: said once per kernel and device, before the first launch.
+// The workgroups ask for more than 64 KiB of LDS: said once per kernel and device, before the first launch
+// (two threads that launch their first traversal at the same time both say it, which is harmless).
 template <typename K> static void allow_large_lds(K kernel)
 {
-    static bool done[16] = {};
+    static std::atomic<uint32_t> done{ 0 };
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || done[dev]) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done[dev] = true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return;
+    if (done.load(std::memory_order_acquire) & (1u << dev)) return;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess)      // the launch that follows fails with a launch error whose cause would otherwise be invisible
+        fprintf(stderr, "mipt: the traversal kernel was refused its LDS size (hipFuncSetAttribute: %s); its launches will fail\n", hipGetErrorString(e));
+    done.fetch_or(1u << dev, std::memory_order_release);
 }
 
 void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
@@ -590,25 +648,26 @@ void launch_closest(const DevScene& S, RayQueue q, const int32_t* d_count, int32
     allow_large_lds(k_trace<0, false, true>); allow_large_lds(k_trace<0, false, false>);
     if (countBoxes)     // the same kernel with one more counter: child boxes that exist in the nodes it visits
         hipLaunchKernelGGL((k_trace<0, false, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
-                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
+                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), (tagInHit ? 1 : 0) | (trace_refill_min() << 8), t.cacheSlots);
     else
         hipLaunchKernelGGL((k_trace<0, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head, hit,
-                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), tagInHit ? 1 : 0, t.cacheSlots);
+                           (float4*)nullptr, (float4*)nullptr, (int64_t)0, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), (tagInHit ? 1 : 0) | (trace_refill_min() << 8), t.cacheSlots);
 }
 void launch_shadow(const DevScene& S, RayQueue q, const int32_t* d_count, const int32_t* d_blockCount, int32_t maxCount, int32_t* d_head,
                    float4* pixState0, float4* pathState, int64_t slotsPerLevel, float eps,
-                   unsigned long long* d_stats, int numCUs, hipStream_t s)
+                   unsigned long long* d_stats, int numCUs, hipStream_t s, bool countBoxes)
 {
     TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
-    int chunk = trace_chunk();
-    if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK;   // must divide a block
+    int chunk = trace_chunk_shadow();
+    if (d_blockCount && (chunk > (1 << MIPT_QBLOCK_SHIFT) || ((1 << MIPT_QBLOCK_SHIFT) % chunk) != 0)) chunk = TRACE_CHUNK_SHADOW;   // must divide a block
     allow_large_lds(k_trace<1, true, false>); allow_large_lds(k_trace<1, false, false>);
-    if (d_blockCount)
-        hipLaunchKernelGGL((k_trace<1, true>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head,
-                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
-    else
-        hipLaunchKernelGGL((k_trace<1, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head,
-                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(), chunk, trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
+    allow_large_lds(k_trace<1, true, true>); allow_large_lds(k_trace<1, false, true>);
+    const int tagArg = trace_refill_min() << 8;
+#define SHADOW_LAUNCH(BLOCKS, COUNT) hipLaunchKernelGGL((k_trace<1, BLOCKS, COUNT>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, d_blockCount, d_head, \
+                           (float4*)nullptr, pixState0, pathState, slotsPerLevel, (uint8_t*)nullptr, eps, d_stats, trace_tri_vote(true), chunk, trace_node_drop(true), trace_tri_stay(true), tagArg, t.cacheSlots)
+    if (d_blockCount) { if (countBoxes) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
+    else { if (countBoxes) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
+#undef SHADOW_LAUNCH
 }
 void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, int32_t maxCount, int32_t* d_head,
                          uint8_t* out, float eps, unsigned long long* d_stats, int numCUs, hipStream_t s)
@@ -616,7 +675,7 @@ void launch_anyhit_flags(const DevScene& S, RayQueue q, const int32_t* d_count, 
     TraceShape t = trace_shape(S, false, maxCount, numCUs, S.numNodeSlots);
     allow_large_lds(k_trace<2, false, false>);
     hipLaunchKernelGGL((k_trace<2, false>), dim3(t.grid), dim3(t.waves * WAVE), t.smem, s, S, q, d_count, (const int32_t*)nullptr, d_head,
-                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(), trace_chunk(), trace_node_drop(), trace_tri_stay(), 0, t.cacheSlots);
+                       (float4*)nullptr, (float4*)nullptr, (float4*)nullptr, (int64_t)0, out, eps, d_stats, trace_tri_vote(true), trace_chunk_shadow(), trace_node_drop(true), trace_tri_stay(true), trace_refill_min() << 8, t.cacheSlots);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -897,7 +956,7 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
     // with one atomic, then shades and writes.  Its shadow rays go to the same block of the shadow
     // queue, packed from the start of the block, and their number to shadowBlockCount: no atomic,
     // and every block of the input writes its count.
-    uint32_t culledCount = 0;
+    uint32_t culledCount = 0, hitCount = 0;
     for (int64_t first = wave * (SHADE_ITEMS * WAVE); first < n; first += numWaves * (SHADE_ITEMS * WAVE)) {
         int total = 0;
         #pragma unroll
@@ -969,8 +1028,13 @@ __global__ void __launch_bounds__(256) k_shade_bounce(DevScene S, DevRender R, R
         }
         if (lane == 0) shadowBlockCount[first >> MIPT_QBLOCK_SHIFT] = shadowRun;
         culledCount += (uint32_t)(total - shadowRun);
+        hitCount += (uint32_t)total;
     }
     if (lane == 0 && culledCount) atomicAdd(&stats[ST_SHADOW_CULLED], (unsigned long long)culledCount);
+    if (lane == 0 && hitCount) {
+        atomicAdd(&stats[ST_SHADE_HITS], (unsigned long long)hitCount);
+        if (spawnLevel) atomicAdd(&stats[ST_SHADE_NEXT], (unsigned long long)hitCount);
+    }
 }
 
 void launch_shade_bounce(const DevScene& S, const DevRender& R, RayQueue q, const float4* hit,

@@ -64,7 +64,9 @@ class Stats(C.Structure):
                 ("closest_triangle_tests", C.c_uint64), ("active_pixels", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
                 ("closest_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("closest_launches", C.c_int32), ("shadow_launches", C.c_int32),
-                ("chunk_samples", C.c_int32), ("samples_done", C.c_int32), ("closest_box_tests", C.c_uint64)]
+                ("chunk_samples", C.c_int32), ("samples_done", C.c_int32), ("closest_box_tests", C.c_uint64),
+                ("shadow_box_tests", C.c_uint64), ("shaded_hits", C.c_uint64), ("bounce_rays_written", C.c_uint64),
+                ("shade_bounce_ms", C.c_double), ("shade_bounce_launches", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

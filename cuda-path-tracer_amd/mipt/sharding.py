@@ -35,10 +35,10 @@ def tile_owner(x, y, width, world, tile_size=32):
     return ((y // tile_size) * tiles_x + (x // tile_size)) % world
 
 
-def reduce_to_rank0(accum, dist=None, world=1):
+def reduce_to_rank0(accum, dist=None, world=1, force=False):
     """Sums the per-rank accumulators (a torch tensor, on the GPU under RCCL or on the CPU under
-    gloo) into rank 0's.  One collective per frame."""
-    if world > 1:
+    gloo) into rank 0's.  One collective per frame.  force: run the collective with one rank too."""
+    if world > 1 or (force and dist is not None):
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
         if getattr(accum, "is_cuda", False):
             # the collective runs on the communicator's stream and the render library on its own:

@@ -124,8 +124,8 @@ typedef struct mipt_params {
                                         the FINAL images of the shards add up to the frame.  0: every shard
                                         traces depth 0 for the whole image (needed when the sums are reduced
                                         and finalized on one rank, as sample-range sharding requires) */
-    int32_t  count_box_tests;        /* 1: mipt_stats.closest_box_tests is filled (the closest-hit kernel then counts the
-                                        child boxes that exist in every node it visits; a few percent slower) */
+    int32_t  count_box_tests;        /* 1: mipt_stats.closest_box_tests and shadow_box_tests are filled (the traversal kernels then
+                                        count the child boxes that exist in every node they visit; a few percent slower) */
 } mipt_params;
 
 typedef struct mipt_build_options {
@@ -171,6 +171,12 @@ typedef struct mipt_stats {
     int32_t  samples_done;           /* first-bounce samples summed into d_accum (all of them unless cancelled) */
     uint64_t closest_box_tests;      /* ray/box tests of the closest-hit queries against child boxes that exist (a node
                                         visit tests 2..4 of them); 0 unless mipt_params.count_box_tests */
+    uint64_t shadow_box_tests;       /* the same for the any-hit queries */
+    uint64_t shaded_hits;            /* hits shaded at depth 1..3 (the bounce-shading kernel) */
+    uint64_t bounce_rays_written;    /* rays that kernel put into the queue of the next depth */
+    double   shade_bounce_ms;        /* summed HIP-event time of the bounce-shading kernel launches (part of shade_ms) */
+    int32_t  shade_bounce_launches;
+    int32_t  reserved;
 } mipt_stats;
 
 /* Replaces CPTCallback::UpdateProgress (PTProgress.h:3-7).  Called on the calling
@@ -204,8 +210,14 @@ int mipt_scene_get_info(const mipt_scene* scene, mipt_scene_info* out);
  * slot (num_node_slots of them): 3 * node_width words of 16-bit box coordinates on the grid
  * returned by mipt_scene_bvh_grid (coordinate = qmin + q * qcell; words 3k .. 3k+2 = x, y, z of
  * child k, each word min | max << 16; an unused child has min > max), then node_width child
- * codes (bit 31 = leaf, low bits = first leaf slot; 0xFFFFFFFF = unused).  Slots that hold no
- * node are zero.  tri_v0/e1/e2: 4 floats per leaf slot. */
+ * codes.  Child codes index ONE space that holds the node slots first and the leaf slots behind
+ * them: a code c < num_node_slots is the inner node in slot c, a code c >= num_node_slots is a
+ * leaf whose first triangle is leaf slot c - num_node_slots (its triangles are consecutive leaf
+ * slots, the last one carries 1 in the fourth float of tri_e1); 0xFFFFFFFF = unused child.
+ * root_code follows the same rule: 0xFFFFFFFF for an empty scene; 0 with num_node_slots == 0 for
+ * a scene that is a single leaf (leaf slot 0); else 0, the root node's slot.  Slots that hold
+ * no node are zero.  tri_v0/e1/e2: 4 floats per leaf slot = (v0, triangle id), (v1 - v0, last
+ * flag), (v2 - v0, 0). */
 int mipt_scene_bvh_sizes(const mipt_scene* scene, int64_t* num_node_slots, int64_t* num_leaf_slots,
                          uint32_t* root_code);
 int mipt_scene_bvh_grid(const mipt_scene* scene, float qmin[3], float qcell[3]);
@@ -220,14 +232,15 @@ int mipt_scene_download_bvh(const mipt_scene* scene, uint32_t* nodes, float* tri
 int mipt_trace_rays(mipt_scene* scene, const float* rays, int64_t num_rays, float epsilon,
                     int32_t* out_tri, float* out_tuv, uint8_t* out_any);
 
-/* The same two queries for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  This entry point has no
- * counterpart in the reference.  d_rays (6 floats per ray) and the three outputs are DEVICE arrays
+/* The same two queries for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc).  This entry point has no counterpart in the reference.  d_rays (6 floats per ray) and the three outputs are DEVICE arrays
  * of the caller, each output may be null; the call allocates and frees nothing: its ray queue, hit
  * records and counters live in a fixed array inside the library's code object (48 bytes per ray,
  * 12.6 MB, one copy per GPU for the life of the process).  At most MIPT_TRACE_DEVICE_MAX_RAYS rays
- * per call, MIPT_E_LIMIT beyond.  The call runs on the scene's stream and returns when the results
- * are complete.  All calls on one GPU share the array: calls that overlap in time race. */
+ * per call, MIPT_E_LIMIT beyond.  The call runs on the scene's own stream and waits for it before it
+ * returns (so it is no call for a thread that is capturing a HIP graph: nothing it launches would
+ * land in that graph, and the wait is not allowed there).  All calls on one GPU share the array:
+ * calls that overlap in time race. */
 #define MIPT_TRACE_DEVICE_MAX_RAYS (1 << 18)
 int mipt_trace_rays_device(mipt_scene* scene, const float* d_rays, int64_t num_rays, float epsilon,
                            int32_t* d_out_tri, float* d_out_tuv, uint8_t* d_out_any);

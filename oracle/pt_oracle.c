@@ -669,9 +669,22 @@ int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p,
                float* out_bgr255, uint32_t* out_dword, int32_t* out_tri,
                int32_t row_step, int32_t row_phase, int threads, pto_stats* stats)
 {
+    return pto_render_window(s, cam, p, accel, out_bgr255, out_dword, out_tri, row_step, row_phase, 0, -1, threads, stats);
+}
+
+/* The same, for the columns [col_begin, col_end) of the sampled rows only (col_end < 0: to the end of the
+ * row): a short run of pixels at full sample count is what a brute-force search can afford. */
+int pto_render_window(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel,
+                      float* out_bgr255, uint32_t* out_dword, int32_t* out_tri,
+                      int32_t row_step, int32_t row_phase, int32_t col_begin, int32_t col_end, int threads, pto_stats* stats)
+{
     if (!s || !cam || !p || cam->div <= 0) return -1;
     long W = cam->client_width / cam->div, H = cam->client_height / cam->div;   /* :478-479 */
     if (row_step <= 0) row_step = 1;
+    if (col_end < 0 || col_end > W) col_end = (int32_t)W;
+    if (col_begin < 0) col_begin = 0;
+    if (col_begin > col_end) col_begin = col_end;
+    const long C0 = col_begin, CW = col_end - col_begin;
     long nNumSamples = p->num_samples;
     if (nNumSamples < 1) nNumSamples = 1;                        /* RayTracerView.cpp:950-951 */
     if (nNumSamples > 10000) nNumSamples = 10000;
@@ -684,14 +697,14 @@ int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p,
     double t0 = now_s();
     /* work items are 32-pixel pieces of the sampled rows, so that a sample of a few rows still
      * keeps every thread busy; pixels are independent (the random stream is keyed by the pixel) */
-    const long PIECE = 32;
+    const long PIECE = CW >= 1024 ? 32 : (CW >= 128 ? 4 : 1);
     long nRows = 0;
     for (long h = 0; h < H; ++h) if ((h % row_step) == row_phase) nRows++;
-    const long piecesPerRow = (W + PIECE - 1) / PIECE;
+    const long piecesPerRow = (CW + PIECE - 1) / PIECE;
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nt) reduction(+:closest,shadow,tt,bt)
     for (long item = 0; item < nRows * piecesPerRow; ++item) {
         long h = row_phase + (item / piecesPerRow) * row_step;
-        long j0 = (item % piecesPerRow) * PIECE, j1 = j0 + PIECE < W ? j0 + PIECE : W;
+        long j0 = C0 + (item % piecesPerRow) * PIECE, j1 = j0 + PIECE < C0 + CW ? j0 + PIECE : C0 + CW;
         rctx R; R.s = s; R.p = p; R.accel = accel; R.closest = R.shadow = R.tri_tests = R.box_tests = 0;
         for (long j = j0; j < j1; ++j) {
             float o[3], d[3];

@@ -106,6 +106,10 @@ void pto_trace_rays(const pto_scene* s, const float* rays, int64_t n, float eps,
 int pto_render(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel,
                float* out_bgr255, uint32_t* out_dword, int32_t* out_tri,
                int32_t row_step, int32_t row_phase, int threads, pto_stats* stats);
+/* The same for the columns [col_begin, col_end) of those rows only (col_end < 0: to the end of the row). */
+int pto_render_window(const pto_scene* s, const mipt_camera* cam, const mipt_params* p, int accel,
+                      float* out_bgr255, uint32_t* out_dword, int32_t* out_tri,
+                      int32_t row_step, int32_t row_phase, int32_t col_begin, int32_t col_end, int threads, pto_stats* stats);
 
 /* The estimator cut the way a multi-GPU run cuts it.  pto_accumulate: for the pixels of shard
  * (p->shard_rank of p->shard_count, square tiles dealt round-robin) and the first-bounce samples

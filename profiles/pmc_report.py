@@ -26,22 +26,31 @@ for r in rows:
             f("TCP_TOTAL_CACHE_ACCESSES_sum"), f("TCP_TCC_READ_REQ_sum"), 1 - f("TCP_TCC_READ_REQ_sum") / max(f("TCP_TOTAL_CACHE_ACCESSES_sum"), 1),
             f("TCC_HIT_sum") / max(f("TCC_REQ_sum"), 1), f("TCC_EA0_RDREQ_sum"), f("FETCH_SIZE") / 1e6, f("WRITE_SIZE") / 1e6))
 
-# optional second argument: write the memory-side traffic of the closest-hit kernel per launch
-# (FETCH_SIZE and WRITE_SIZE are KiB at the L2's fabric side, Infinity-Cache hits included; on gfx950
-# FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled) for bench.py to report
-if len(sys.argv) > 3:
+# optional arguments <traffic.json> <workload> <source sha1>: write the fabric-side traffic per launch of the three
+# hot kernels (FETCH_SIZE and WRITE_SIZE are KiB at the L2's fabric side, Infinity-Cache hits included; on gfx950
+# FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled) for bench.py to report.  The hash of the kernel
+# sources the counters were taken on is stored with them (pmc_passes.sh writes it to source_sha1.txt on the box):
+# bench.py quotes an entry only while the tree still holds those sources.
+if len(sys.argv) > 4:
     import json
-    out, workload = sys.argv[2], sys.argv[3]
-    for r in rows:
-        if "k_trace<0, false, false>" in r["kernel"]:      # the timed instance (the counting instance runs once more, untimed)
-            calls = float(r["calls"])
-            fetch, write = float(r["FETCH_SIZE"]) * 1024, float(r["WRITE_SIZE"]) * 1024
-            try:
-                table = json.load(open(out))
-            except (OSError, ValueError):
-                table = {}
-            table[workload] = {"bytes_per_launch": (2 * fetch + write) / calls, "fetch_size_bytes_raw": fetch / calls,
-                               "write_size_bytes": write / calls, "launches_profiled": int(calls),
-                               "note": "2 x FETCH_SIZE + WRITE_SIZE per launch of k_trace<0>; fabric side of L2, Infinity Cache hits included"}
-            json.dump(table, open(out, "w"), indent=1)
-            print("traffic per launch: %.2f GB" % (table[workload]["bytes_per_launch"] / 1e9))
+    out, workload, sha = sys.argv[2], sys.argv[3], sys.argv[4]
+    # the timed closest-hit instance (the counting instance runs once more, untimed), the any-hit instance of the
+    # bounce levels, bounce shading
+    wanted = {"k_trace<0>": "k_trace<0, false, false>", "k_trace<1>": "k_trace<1, true, false>", "k_shade_bounce": "k_shade_bounce"}
+    try:
+        table = json.load(open(out))
+    except (OSError, ValueError):
+        table = {}
+    entry = {}
+    for key, name in wanted.items():
+        for r in rows:
+            if name in r["kernel"] and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+                calls = float(r["calls"])
+                fetch, write = float(r["FETCH_SIZE"]) * 1024, float(r["WRITE_SIZE"]) * 1024
+                entry[key] = {"bytes_per_launch": (2 * fetch + write) / calls, "fetch_size_bytes_raw": fetch / calls,
+                              "write_size_bytes": write / calls, "launches_profiled": int(calls), "source_sha1": sha,
+                              "note": "2 x FETCH_SIZE + WRITE_SIZE per launch; fabric side of L2, Infinity Cache hits included"}
+                print("traffic per launch of %s: %.2f GB" % (key, entry[key]["bytes_per_launch"] / 1e9))
+                break
+    table[workload] = entry
+    json.dump(table, open(out, "w"), indent=1)

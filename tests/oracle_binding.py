@@ -60,6 +60,8 @@ def lib():
                                      C.c_void_p, C.c_int]
         L.pto_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.POINTER(OStats)]
+        L.pto_render_window.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.POINTER(OStats)]
         L.pto_accumulate.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p, C.c_int]
         L.pto_finalize.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Params), C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int]
@@ -133,14 +135,16 @@ class OracleScene:
                              anyhit.ctypes.data, threads)
         return tri, tuv, anyhit
 
-    def render(self, cam, params, accel=ACCEL_OCTREE, row_step=1, row_phase=0, threads=0):
+    def render(self, cam, params, accel=ACCEL_OCTREE, row_step=1, row_phase=0, threads=0, cols=None):
+        """cols = (begin, end): only these columns of the sampled rows are rendered."""
         w, h = cam.image_size
         img = np.zeros((h, w, 3), dtype=np.float32)
         dword = np.zeros((h, w), dtype=np.uint32)
         tri = np.full((h, w), -2, dtype=np.int32)
         st = OStats()
-        rc = lib().pto_render(self._h, C.byref(cam), C.byref(params), accel, img.ctypes.data, dword.ctypes.data,
-                              tri.ctypes.data, row_step, row_phase, threads, C.byref(st))
+        c0, c1 = cols if cols is not None else (0, -1)
+        rc = lib().pto_render_window(self._h, C.byref(cam), C.byref(params), accel, img.ctypes.data, dword.ctypes.data,
+                                     tri.ctypes.data, row_step, row_phase, c0, c1, threads, C.byref(st))
         if rc != 0:
             raise RuntimeError("pto_render failed")
         return img, dword, tri, st

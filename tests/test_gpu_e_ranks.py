@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(ranks, shard, dump):
+def _bench(ranks, shard, dump, extra_env=None):
     args = ["--gpus", str(ranks), "--steps", "1", "--warmup", "0", "--workload", "crytek_gi16_270p", "--no-cpu-baseline",
             "--shard", shard, "--dump-image", str(dump)]
     if ranks == 1:
@@ -34,6 +34,7 @@ def _bench(ranks, shard, dump):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH] + args
     env = dict(os.environ, MIPT_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    env.update(extra_env or {})
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -54,3 +55,17 @@ def test_two_ranks_render_the_one_rank_image(tmp_path):
     # a pixel's samples come from two ranks: equal up to the fp32 order of the sum
     assert np.allclose(img_s, img1, rtol=1e-5, atol=1e-3)
     assert (img_s == img1).mean() > 0.5
+
+
+def test_one_rank_reduces_through_rccl(tmp_path):
+    """The collective path of a multi-GPU run on the one GPU at hand: a one-rank `nccl` (= RCCL) process group is
+    created after the device has been chosen, the accumulator (sample shards) or the final image (tile shards) goes
+    through torch.distributed.reduce on the GPU, and the library's own stream then reads what the collective's
+    stream wrote.  The image must be the one of the plain run."""
+    plain, img0 = _bench(1, "tiles", tmp_path / "plain.npy")
+    for shard in ("tiles", "samples"):
+        env = {"MIPT_BENCH_BACKEND": "nccl", "MIPT_BENCH_FORCE_PG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+               "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+        res, img = _bench(1, shard, tmp_path / f"rccl_{shard}.npy", env)
+        assert res["config"]["process_group"] == "ncclx1"
+        assert res["config"]["image_sha1"] == plain["config"]["image_sha1"] and np.array_equal(img, img0)

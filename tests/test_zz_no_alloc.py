@@ -1,10 +1,12 @@
 """mipt_trace_rays_device, the entry point that allocates nothing (its ray queue, hit records and
-counters live in a fixed array inside the library), against mipt_trace_rays on the same rays:
-triangle ids, (t, ua, va) bit patterns and any-hit flags must be identical.  Two calls in a row
-share the array; the second is smaller, so stale entries of the first lie behind its end."""
+counters live in a fixed array inside the library), against mipt_trace_rays on the same rays and
+against the CPU oracle's brute-force search: triangle ids, (t, ua, va) bit patterns and any-hit
+flags must be identical.  Two calls in a row share the array; the second is smaller, so stale
+entries of the first lie behind its end.  The device's free memory is read before and after a call."""
 import numpy as np
 import pytest
 
+import oracle_binding as ob
 import scenes
 from mipt import abi
 
@@ -24,7 +26,7 @@ def _run(gpu, sc, rays):
     return d_tri.to_host(np.int32), d_tuv.to_host(np.float32).reshape(n, 3), d_any.to_host(np.uint8)
 
 
-def test_trace_rays_device_matches_trace_rays_on_two_calls(gpu, atrium_small):
+def test_trace_rays_device_matches_trace_rays_and_the_oracle_on_two_calls(gpu, atrium_small, atrium_small_oracle):
     sc = gpu.Scene(atrium_small.desc)
     for n, seed in ((60000, 5), (7001, 6)):
         rays = scenes.random_rays(atrium_small, n, seed=seed)
@@ -34,6 +36,26 @@ def test_trace_rays_device_matches_trace_rays_on_two_calls(gpu, atrium_small):
         assert np.array_equal(dtri, tri), f"ids differ at n={n}"
         assert np.array_equal(dtuv.view(np.uint32), tuv.view(np.uint32)), f"(t, ua, va) differ at n={n}"
         assert np.array_equal(dany, anyhit), f"any-hit flags differ at n={n}"
+        # and directly against the oracle (the two entry points share their kernels: a fault common to both would pass the lines above)
+        otri, otuv, oany = atrium_small_oracle.trace_rays(rays, accel=ob.ACCEL_BRUTE)
+        assert np.array_equal(dtri, otri) and np.array_equal(dany, oany)
+        assert np.array_equal(dtuv.view(np.uint32), otuv.view(np.uint32))
+
+
+def test_trace_rays_device_leaves_the_free_memory_as_it_was(gpu, atrium_small):
+    torch = pytest.importorskip("torch")
+    sc = gpu.Scene(atrium_small.desc)
+    n = 50000
+    rays = scenes.random_rays(atrium_small, n, seed=12)
+    d_rays, d_tri, d_tuv, d_any = (gpu.DeviceBuffer(24 * n), gpu.DeviceBuffer(4 * n), gpu.DeviceBuffer(12 * n), gpu.DeviceBuffer(n))
+    d_rays.from_host(rays)
+    sc.trace_rays_device(d_rays.ptr, n, 1e-20, d_tri.ptr, d_tuv.ptr, d_any.ptr)      # first call: kernels are loaded, attributes set
+    torch.cuda.mem_get_info(0)                                                        # (the query itself initialises torch's context)
+    before = torch.cuda.mem_get_info(0)[0]
+    for _ in range(3):
+        sc.trace_rays_device(d_rays.ptr, n, 1e-20, d_tri.ptr, d_tuv.ptr, d_any.ptr)
+    after = torch.cuda.mem_get_info(0)[0]
+    assert after == before, f"free device memory changed by {before - after} bytes over three calls"
 
 
 def test_trace_rays_device_outputs_are_optional_and_the_limit_is_an_error(gpu, atrium_small):
