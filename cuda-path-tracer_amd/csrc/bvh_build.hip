@@ -412,28 +412,14 @@ __device__ __forceinline__ uint32_t child_code(const BNode& c, int id)
 
 struct QuantGrid { float qmin[3], invCell[3]; };
 
-#ifdef MIPT_EMULATE_F16_PLANES
-// experiment: the grid coordinates a 16-bit float could hold (11 significant bits around the scene centre), rounded outwards
-__device__ __forceinline__ float f16_grid(float q, bool up)
-{
-    float c = q - 32768.0f, a = fabsf(c);
-    if (a < 2048.0f) return q;
-    int e; frexpf(a, &e);                 // a = m * 2^e, m in [0.5, 1): 11 significant bits -> step 2^(e - 11)
-    float step = ldexpf(1.0f, e - 11);
-    float r = up ? ceilf(c / step) * step : floorf(c / step) * step;
-    return r + 32768.0f;
-}
-#else
-__device__ __forceinline__ float f16_grid(float q, bool) { return q; }
-#endif
 __device__ __forceinline__ uint32_t quant_lo(float v, float qmin, float invCell)
 {
-    float q = f16_grid(floorf((v - qmin) * invCell), false);
+    float q = floorf((v - qmin) * invCell);
     return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f);
 }
 __device__ __forceinline__ uint32_t quant_hi(float v, float qmin, float invCell)
 {
-    float q = f16_grid(ceilf((v - qmin) * invCell), true);
+    float q = ceilf((v - qmin) * invCell);
     return (uint32_t)fminf(fmaxf(q, 0.0f), 65535.0f);
 }
 

@@ -658,6 +658,13 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                     spanBegin(1);
                     launch_shadow(S, f->shadowQ, inCount, f->shadowBlocks, (int32_t)slots, Lc + 2, f->pixState, f->pathState, slots, R.eps, f->stats, g_numCUs, st, R.countBoxTests != 0);
                     spanEnd();
+                    if (progress && level < 3) {
+                        // the reference reports every integer percent (PathTracer.cu:726-731): between the passes the
+                        // work done is reported after every depth.  The sums handed over so far are those of the
+                        // passes that are complete (samples_done is unchanged until this pass ends).
+                        HIPTRY(hipStreamSynchronize(st));
+                        progress(total * ((int64_t)(n0 - sb) * 3 + (int64_t)Sn * level) / ((int64_t)(se - sb) * 3), total, user);
+                    }
                 }
                 launch_resolve(R, f->pathState, slots, f->actPix, nAct, n0, Sn, f->pixAccum, st);
                 f->samplesDone = n0 + Sn - sb;

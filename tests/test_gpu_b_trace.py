@@ -78,6 +78,34 @@ def test_empty_and_ragged_batches(gpu, cornell, cornell_oracle):
     assert_trace_parity(sc, cornell_oracle, rays)
 
 
+def test_rays_that_start_on_box_planes(gpu, atrium_small, atrium_small_oracle):
+    """Origins exactly on planes of node boxes (entry distance +0 or -0 on that axis), directions along the axes and
+    oblique: the sort key of a box the ray starts on must not turn into the farthest one (the sign bit of a -0 is
+    no part of the key), so nothing behind such a box is dropped."""
+    sc = gpu.Scene(atrium_small.desc)
+    nodes, _, _, _, root, (qmin, qcell) = sc.download_bvh()
+    W = sc.info().node_width
+    words = nodes[:256, :3 * W].reshape(-1, W, 3)
+    codes = nodes[:256, 3 * W:]
+    rng = np.random.default_rng(21)
+    rays = []
+    for n in range(words.shape[0]):
+        for k in range(W):
+            if codes[n, k] == 0xFFFFFFFF:
+                continue
+            lo = qmin + (words[n, k] & 0xFFFF).astype(np.float32) * qcell
+            hi = qmin + (words[n, k] >> 16).astype(np.float32) * qcell
+            for axis in range(3):
+                for plane in (lo, hi):
+                    o = (lo + (hi - lo) * rng.random(3).astype(np.float32)).astype(np.float32)
+                    o[axis] = plane[axis]
+                    for d in (np.eye(3, dtype=np.float32)[axis], -np.eye(3, dtype=np.float32)[axis], rng.normal(0, 1, 3).astype(np.float32)):
+                        rays.append(np.concatenate([o, d / np.linalg.norm(d)]))
+    rays = np.asarray(rays, dtype=np.float32)[:60000]
+    tri = assert_trace_parity(sc, atrium_small_oracle, rays)
+    assert (tri >= 0).mean() > 0.5
+
+
 def test_deep_tree_uses_the_stack_beyond_lds(gpu):
     """Nested shells of triangles whose sizes fall geometrically give a tall, thin tree; rays
     through the common centre enter every child box on the way down, so the per-lane stack grows

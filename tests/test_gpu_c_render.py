@@ -201,7 +201,9 @@ def test_progress_callback_contract(gpu, cornell):
     sc.render(cam, prm, progress=lambda done, total, user: calls.append((done, total)))
     total = 240 * 135
     assert calls[0] == (0, total) and calls[-1] == (total, total)           # PathTracer.cu:721, 726-731
-    assert all(b[0] >= a[0] for a, b in zip(calls, calls[1:])) and len(calls) == 1 + 4
+    # four passes of two samples: a call after every depth of every pass (the last depth coincides with the end of the pass)
+    assert all(b[0] >= a[0] for a, b in zip(calls, calls[1:])) and len(calls) == 1 + 4 * 3
+    assert len(set(calls)) == len(calls), "every call reports more work than the one before"
 
 
 def test_invalid_arguments_are_rejected(gpu, cornell):
@@ -230,7 +232,8 @@ def test_cancel_and_partial_image(gpu, cornell):
     previews = []
 
     def progress(done, total, user):
-        if done > 0:
+        # call-backs come after every depth of a pass; the sums (and samples_done) change when a pass ends
+        if done > 0 and (not previews or previews[-1][0] != fr.samples_done):
             fr.finalize_partial(acc.ptr, fr.samples_done, out.ptr)
             previews.append((fr.samples_done, out.to_host().reshape(135, 240, 3).copy()))
         if fr.samples_done == 4:
@@ -239,8 +242,12 @@ def test_cancel_and_partial_image(gpu, cornell):
     with pytest.raises(gpu.MiptCancelled) as ei:
         fr.accumulate(acc.ptr, progress=progress)
     assert ei.value.stats.samples_done == 4 and fr.samples_done == 4
-    assert [n for n, _ in previews] == [2, 4]
+    assert [n for n, _ in previews] == [0, 2, 4]           # 0: a call-back inside the first pass sees the direct-light image
     for n, img in previews:
+        if n == 0:
+            ref, _, _ = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=0, num_samples=1))
+            assert np.array_equal(img, ref), "partial image before the first pass ends"
+            continue
         ref, _, _ = sc.render(cam, host.default_params(sun_pos=sun, global_illumination=1, num_samples=n))
         assert np.array_equal(img, ref), f"partial image after {n} samples"
     # the flag is consumed: the next call runs to the end
