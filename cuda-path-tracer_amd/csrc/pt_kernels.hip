@@ -159,11 +159,11 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 #define TRACE_CHUNK_SHADOW 512
 #define TRACE_WAVES 12            // waves per workgroup
 #define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
-#define TRACE_TRI_VOTE 16
-#define TRACE_NODE_DROP 28
+#define TRACE_TRI_VOTE 12
+#define TRACE_NODE_DROP 24
 #define TRACE_REFILL_MIN 1     // idle lanes a wave waits for before it hands out new rays
-#define TRACE_TRI_VOTE_SHADOW 16
-#define TRACE_NODE_DROP_SHADOW 28
+#define TRACE_TRI_VOTE_SHADOW 12
+#define TRACE_NODE_DROP_SHADOW 24
 #define TRACE_TRI_STAY_SHADOW 3
 #define TRACE_TRI_STAY 3      // triangle steps repeat while more than this many eighths of the entering lanes stay at a leaf (0 = one step)
 static_assert(MIPT_NODE_WIDTH == 4, "the node step is written for four-wide nodes");
@@ -398,6 +398,74 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         cur = occluded ? LANE_FINISHED : next;
     };
 
+#ifndef MIPT_NO_COOP_LEAF
+    // A triangle step in which the lanes that have no leaf help the lanes that have one.  The k-th lane
+    // without a leaf takes the SECOND triangle of the leaf of the k-th lane with one (the ray travels through
+    // ds_bpermute), tests it at the same time as the owner tests the first, and the owner takes the result over if
+    // its own triangle was not the last of the leaf.  Run by ALL lanes of the wave (the lane exchange needs every lane).
+    auto shfl_u = [&](int srcLane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)v); };
+    auto shfl_f = [&](int srcLane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(srcLane << 2, __float_as_int(v))); };
+    auto tri_step_coop = [&](bool lds) {
+        const bool owner = at_leaf(cur);
+        const unsigned long long om = __ballot(owner);
+        const int T = __popcll(om), H = WAVE - T;
+        const int orank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+        const int hrank = lane - orank;                       // lanes without a leaf before this one
+        // tab: the lanes in the order "owners first": lane p of tab holds the id of the p-th owner, lane T + h the h-th helper
+        const int pos = owner ? orank : T + hrank;
+        const int tab = __builtin_amdgcn_ds_permute(pos << 2, lane);
+        const bool helper = !owner && hrank < T;
+        const bool helped = owner && orank < H;
+        const int partner = __builtin_amdgcn_ds_bpermute((owner ? T + orank : hrank) << 2, tab);
+        const int src = helper ? partner : lane;
+        F3 po = f3(shfl_f(src, o.x), shfl_f(src, o.y), shfl_f(src, o.z)), pd = f3(shfl_f(src, d.x), shfl_f(src, d.y), shfl_f(src, d.z));
+        const uint32_t pcur = shfl_u(src, cur);
+        uint32_t slot = pcur - leafBase + (helper ? 1u : 0u);
+        slot = slot < numLeaf ? slot : numLeaf - 1;             // a helper's triangle may lie beyond the owner's leaf, even beyond the array
+        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+        uint32_t upper = LANE_FINISHED, lower = LANE_FINISHED;
+        if (owner | helper) {
+            const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
+            a = tr[0]; b = tr[1]; c = tr[2];
+        }
+        if (owner) rows_below(lds, upper, lower);
+        float t, u, v;
+        bool accept = ray_triangle_all(po, pd, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v);
+        if (MODE != 0) accept = accept & (t < FLT_MAX);
+        const int32_t id = (int32_t)__float_as_uint(a.w);
+        const bool last1 = (__float_as_uint(b.w) != 0) | (slot + 1 >= numLeaf);
+        // what the owner learns from its helper: (t, u, v) and the id with two flags above it
+        const uint32_t packed = ((uint32_t)id & 0x3fffffffu) | (accept ? 0x80000000u : 0u) | (last1 ? 0x40000000u : 0u);
+        const float ht = shfl_f(partner, t), hu = shfl_f(partner, u), hv = shfl_f(partner, v);
+        const uint32_t hp = shfl_u(partner, packed);
+        const bool use2 = helped & !last1;
+        const bool acc2 = use2 & ((hp >> 31) != 0);
+        const bool last2 = (hp & 0x40000000u) != 0;
+        const int32_t id2 = (int32_t)(hp & 0x3fffffffu);
+        triCount += (owner ? 1u : 0u) + (use2 ? 1u : 0u);
+        bool occluded = false;
+        if (MODE != 0) {
+            occluded = owner & (accept | acc2);
+            best.tri = (owner & accept) ? id : ((owner & acc2) ? id2 : best.tri);
+        } else {
+            bool better = owner & accept & ((t < best.t) | ((t == best.t) & (id < best.tri)));
+            best.t = better ? t : best.t; best.u = better ? u : best.u; best.v = better ? v : best.v; best.tri = better ? id : best.tri;
+            bool better2 = acc2 & ((ht < best.t) | ((ht == best.t) & (id2 < best.tri)));
+            best.t = better2 ? ht : best.t; best.u = better2 ? hu : best.u; best.v = better2 ? hv : best.v; best.tri = better2 ? id2 : best.tri;
+            tcull = (better | better2) ? best.t * 1.0000153f : tcull;
+            cullEntry = __float_as_uint(tcull) | slotMask;
+        }
+        const bool last = last1 | (use2 & last2);
+        uint32_t old; int rows;
+        take(upper, lower, old, rows);
+        if (owner) {
+            sp -= last ? rows : 0;
+            uint32_t next = last ? (old & slotMask) : cur + (use2 ? 2u : 1u);
+            cur = occluded ? LANE_FINISHED : next;
+        }
+    };
+#endif
+
     for (;;) {
 #ifdef MIPT_TRACE_PROFILE
         pOuter++;
@@ -479,9 +547,13 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_PROFILE
                 pTriIters++;
 #endif
+#ifndef MIPT_NO_COOP_LEAF
+                tri_step_coop(__ballot(at_leaf(cur) && sp > ldsCap) == 0);
+#else
                 if (at_leaf(cur)) {
                     tri_step(__ballot(sp > ldsCap) == 0);
                 }
+#endif
             } while (triStay > 0 && __popcll(__ballot(at_leaf(cur))) > triKeep);
         };
         // the triangle phase follows the node phase in the same round
