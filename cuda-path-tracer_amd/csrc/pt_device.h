@@ -171,7 +171,11 @@ __device__ __forceinline__ bool box_test(const BoxRay& r, uint32_t wx, uint32_t 
     float y0 = __builtin_fmaf((float)(py & 0xffffu), r.iy, r.ny), y1 = __builtin_fmaf((float)(py >> 16), r.iy, r.ny);
     float z0 = __builtin_fmaf((float)(pz & 0xffffu), r.iz, r.nz), z1 = __builtin_fmaf((float)(pz >> 16), r.iz, r.nz);
     float tmin = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
-    float tmax = CULL ? fminf(fminf(x1, y1), fminf(z1, tcull)) : fminf(fminf(x1, y1), z1);
+    float zc = z1;
+    // the minimum with tcull as the bare instruction: tcull is never a NaN, which the compiler cannot know (it
+    // would first bring the value into canonical form, one more instruction per node step)
+    if (CULL) asm("v_min_f32 %0, %1, %2" : "=v"(zc) : "v"(z1), "v"(tcull));
+    float tmax = fminf(fminf(x1, y1), zc);
     tnear = tmin; tfar = tmax;
     return tmin <= tmax;
 }

@@ -20,6 +20,12 @@
 
 #define WAVE 64
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// with -DMIPT_ISA_MARKERS the traversal steps are bracketed by comments in the assembly (profiles/isa_loops.py cuts them out)
+#ifdef MIPT_ISA_MARKERS
+#define ISA_MARK(text) asm volatile("; MIPT " text)
+#else
+#define ISA_MARK(text) do { } while (0)
+#endif
 // queue entries a wave of a shading kernel handles per reservation in its output queues
 #define SHADE_ITEMS 16
 
@@ -195,11 +201,11 @@ __device__ __forceinline__ uint32_t stack_load(const uint32_t* lds, const uint32
 #define ENTRY_MISS 0u
 #define CULL_NONE  0x7fffffffu     // no hit yet: every entry passes
 template <int MODE>
-__device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t keyMask, int& hits)
+__device__ __forceinline__ uint32_t box_entry(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, uint32_t code, uint32_t keyMask, unsigned long long& hitLanes)
 {
     float t0, t1;
     bool h = box_test<MODE == 0>(r, wx, wy, wz, tcull, t0, t1);
-    hits += h;
+    hitLanes = __ballot(h);          // the lanes of the wave that hit this child: the compare's own result, no further instruction
     uint32_t key = (MODE != 0) ? 0x7f7fffffu - __float_as_uint(t1 - t0) : __float_as_uint(t0);
     uint32_t e = code | (key & keyMask);      // codes of children that exist are below slotMask; a child that does not exist is always missed
     return h ? e : ENTRY_MISS;
@@ -232,8 +238,12 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     const uint32_t LANE_FINISHED = leafBase + numLeaf;      // ray done, result not yet written; also the entry in the two bottom rows of the stack
     const uint32_t LANE_IDLE = LANE_FINISHED + 1;           // no ray
     for (int i = threadIdx.x; i < cacheSlots * MIPT_NODE_U4; i += blockDim.x) smem4[i] = nodes[i];
+    // The node copy starts at LDS address 0 (the kernel has no other LDS object), so a node's byte offset in the tree
+    // is also its LDS address in the copy.  Checked, not assumed: a build that places it elsewhere stops here.
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem4 != 0u) __builtin_trap();
     uint32_t* stack = (uint32_t*)(smem4 + (size_t)cacheSlots * MIPT_NODE_U4) + (size_t)waveInGroup * ldsCap * WAVE + lane;
     stack[0] = LANE_FINISHED; stack[WAVE] = LANE_FINISHED;          // never overwritten: a ray's own rows start at 2
+    const uint32_t* stackBelow = stack - 2 * WAVE;                  // stackBelow + sp * WAVE = the lower of the two rows below the stack pointer
     __syncthreads();
     const int n = *d_count;
     // per-wave slice of the spill area
@@ -288,13 +298,14 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     // The two rows below the stack pointer.  `lds`: they are in the LDS part for every lane of the wave (the
     // caller has checked), the common case.
     auto rows_below = [&](bool lds, uint32_t& upper, uint32_t& lower) {
-        if (__builtin_expect(lds, 1)) { const uint32_t* st = stack + (sp - 2) * WAVE; lower = st[0]; upper = st[WAVE]; }
+        if (__builtin_expect(lds, 1)) { const uint32_t* st = stackBelow + sp * WAVE; lower = st[0]; upper = st[WAVE]; }
         else {
             upper = stack_load(stack, spill, ldsCap, sp - 1, LANE_FINISHED); lower = stack_load(stack, spill, ldsCap, sp - 2, LANE_FINISHED);
             asm volatile("" : "+v"(upper), "+v"(lower));      // keeps these loads apart from the LDS reads of the common case (merged, both would become flat loads)
         }
     };
     auto node_step = [&](bool lds) {
+        ISA_MARK("node step begin");
         // The node slot as words: 3k .. 3k+2 = box of child k, 12 .. 15 = child codes.  The top of the tree is
         // read from the workgroup's copy in LDS, the rest from memory, into the same registers: the lanes of
         // either kind issue their four 16-byte loads under their own exec mask and the wave then waits once
@@ -307,8 +318,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         unsigned long long ablX0 = 0, ablX1 = 0, ablX2 = 0;
 #endif
         {
-            const uint32_t ldsAddr = (uint32_t)(size_t)(smem4 + (size_t)cur * MIPT_NODE_U4);
-            const uint4* gaddr = nodes + (size_t)cur * MIPT_NODE_U4;
+            // byte offset of the node slot: the same number in the tree (32 bits: the builder keeps the node array below 4 GiB)
+            // and in the copy, which starts at the workgroup's LDS base
+            const uint32_t nodeOff = cur * (uint32_t)(MIPT_NODE_U4 * sizeof(uint4));
+            const uint32_t ldsAddr = nodeOff;
             unsigned long long saved;
             asm volatile(
                 "v_cmp_gt_u32_e32 vcc, %[cs], %[cur]\n\t"
@@ -318,14 +331,14 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                 "ds_read_b128 %[q2], %[la] offset:32\n\t"
                 "ds_read_b128 %[q3], %[la] offset:48\n\t"
                 "s_andn2_b64 exec, %[sv], vcc\n\t"
-                "global_load_dwordx4 %[q0], %[ga], off\n\t"
-                "global_load_dwordx4 %[q1], %[ga], off offset:16\n\t"
-                "global_load_dwordx4 %[q2], %[ga], off offset:32\n\t"
-                "global_load_dwordx4 %[q3], %[ga], off offset:48\n\t"
+                "global_load_dwordx4 %[q0], %[go], %[gb]\n\t"
+                "global_load_dwordx4 %[q1], %[go], %[gb] offset:16\n\t"
+                "global_load_dwordx4 %[q2], %[go], %[gb] offset:32\n\t"
+                "global_load_dwordx4 %[q3], %[go], %[gb] offset:48\n\t"
 #ifdef MIPT_ABLATE_LOAD
-                "global_load_dwordx2 %[x0], %[ga], off offset:8\n\t"
-                "global_load_dwordx2 %[x1], %[ga], off offset:24\n\t"
-                "global_load_dwordx2 %[x2], %[ga], off offset:40\n\t"
+                "global_load_dwordx2 %[x0], %[go], %[gb] offset:8\n\t"
+                "global_load_dwordx2 %[x1], %[go], %[gb] offset:24\n\t"
+                "global_load_dwordx2 %[x2], %[go], %[gb] offset:40\n\t"
 #endif
                 "s_mov_b64 exec, %[sv]\n\t"
                 "s_waitcnt vmcnt(0) lgkmcnt(0)"
@@ -333,11 +346,43 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_ABLATE_LOAD
                   , [x0] "=&v"(ablX0), [x1] "=&v"(ablX1), [x2] "=&v"(ablX2)
 #endif
-                : [cs] "s"((uint32_t)cacheSlots), [cur] "v"(cur), [la] "v"(ldsAddr), [ga] "v"(gaddr)
+                : [cs] "s"((uint32_t)cacheSlots), [cur] "v"(cur), [la] "v"(ldsAddr), [go] "v"(nodeOff), [gb] "s"(nodes)
                 : "vcc", "memory");
         }
 #ifdef MIPT_ABLATE_LOAD
         ablAcc ^= (uint32_t)(ablX0 ^ ablX1 ^ ablX2);
+#endif
+        // What a group of the node step's own instructions costs: the same number of them once more, independent
+        // of each other, on registers nothing reads.  (Taking them out would change the result; adding them does not.)
+#ifdef MIPT_ABLATE_ALIGNBIT      // the 12 near/far rotations of box_test
+        {
+            uint32_t x0, x1, x2, x3;
+            asm volatile("v_alignbit_b32 %0, %4, %4, 16\n\tv_alignbit_b32 %1, %5, %5, 16\n\tv_alignbit_b32 %2, %6, %6, 16\n\tv_alignbit_b32 %3, %7, %7, 16\n\t"
+                         "v_alignbit_b32 %0, %5, %5, 15\n\tv_alignbit_b32 %1, %6, %6, 15\n\tv_alignbit_b32 %2, %7, %7, 15\n\tv_alignbit_b32 %3, %4, %4, 15\n\t"
+                         "v_alignbit_b32 %0, %6, %6, 14\n\tv_alignbit_b32 %1, %7, %7, 14\n\tv_alignbit_b32 %2, %4, %4, 14\n\tv_alignbit_b32 %3, %5, %5, 14"
+                         : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w));
+        }
+#endif
+#ifdef MIPT_ABLATE_CVT           // the 24 conversions of 16-bit planes to float
+        {
+            float x0, x1, x2, x3;
+            #pragma unroll
+            for (int r = 0; r < 3; r++)
+                asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\tv_cvt_f32_u32_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                             "v_cvt_f32_u32_sdwa %2, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\tv_cvt_f32_u32_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                             "v_cvt_f32_u32_sdwa %0, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\tv_cvt_f32_u32_sdwa %1, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
+                             "v_cvt_f32_u32_sdwa %2, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\tv_cvt_f32_u32_sdwa %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w));
+        }
+#endif
+#ifdef MIPT_ABLATE_FMA           // 24 multiply-adds (the plane distances)
+        {
+            float x0, x1, x2, x3;
+            #pragma unroll
+            for (int r = 0; r < 6; r++)
+                asm volatile("v_fma_f32 %0, %4, %5, %6\n\tv_fma_f32 %1, %5, %6, %7\n\tv_fma_f32 %2, %6, %7, %4\n\tv_fma_f32 %3, %7, %4, %5"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
+        }
 #endif
         const u32x4 q4[MIPT_NODE_U4] = { q0, q1, q2, q3 };
         auto word = [&](int i) -> uint32_t { const u32x4& v = q4[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
@@ -348,10 +393,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         }
         // one entry per child, ENTRY_MISS where the ray misses the child's box
         uint32_t e[MIPT_NODE_WIDTH];
-        int hits = 0;
+        unsigned long long hitLanes[MIPT_NODE_WIDTH];
         #pragma unroll
         for (int k = 0; k < MIPT_NODE_WIDTH; k++)
-            e[k] = box_entry<MODE>(br, word(3 * k), word(3 * k + 1), word(3 * k + 2), tcull, word(3 * MIPT_NODE_WIDTH + k), keyMask, hits);
+            e[k] = box_entry<MODE>(br, word(3 * k), word(3 * k + 1), word(3 * k + 2), tcull, word(3 * MIPT_NODE_WIDTH + k), keyMask, hitLanes[k]);
         // a network of compare-exchanges sorts the entries, largest (farthest) first
         order_pair(e[0], e[1]); order_pair(e[2], e[3]);
         order_pair(e[0], e[2]); order_pair(e[1], e[3]);
@@ -360,7 +405,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         // the nearest one on top, the misses above it
         if (__builtin_expect(lds, 1)) { uint32_t* st = stack + sp * WAVE; st[0] = e[0]; st[WAVE] = e[1]; st[2 * WAVE] = e[2]; st[3 * WAVE] = e[3]; }
         else { stack_store(stack, spill, ldsCap, sp, e[0]); stack_store(stack, spill, ldsCap, sp + 1, e[1]); stack_store(stack, spill, ldsCap, sp + 2, e[2]); stack_store(stack, spill, ldsCap, sp + 3, e[3]); }
-        sp += hits;
+        // the stack pointer rises by the number of children hit: four additions of 0 with the lane's bit of a hit mask as carry
+        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %2\n\t"
+            "v_addc_co_u32_e64 %0, vcc, 0, %0, %3\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %4"
+            : "+v"(sp) : "s"(hitLanes[0]), "s"(hitLanes[1]), "s"(hitLanes[2]), "s"(hitLanes[3]) : "vcc");
         // and the lane goes on with one of the two rows below the new stack pointer: the nearest child if one was hit
         // (it cannot lie beyond the best hit: its box has just been tested against it), else an older entry
         uint32_t upper, lower, next; int rows;
@@ -368,6 +416,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         take(upper, lower, next, rows);
         sp -= rows;
         cur = next & slotMask;
+        ISA_MARK("node step end");
     };
     // the exact triangle test on one triangle of the lane's leaf
     auto tri_step = [&](bool lds) {
@@ -405,27 +454,30 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     // its own triangle was not the last of the leaf.  Run by ALL lanes of the wave (the lane exchange needs every lane).
     auto shfl_u = [&](int srcLane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)v); };
     auto shfl_f = [&](int srcLane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(srcLane << 2, __float_as_int(v))); };
-    auto tri_step_coop = [&](bool lds) {
-        const bool owner = at_leaf(cur);
-        const unsigned long long om = __ballot(owner);
+    auto tri_step_coop = [&](bool lds, unsigned long long om) {      // om: the lanes at a leaf
+        ISA_MARK("triangle step begin");
+        const bool owner = __builtin_amdgcn_inverse_ballot_w64(om);
         const int T = __popcll(om), H = WAVE - T;
         const int orank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
         const int hrank = lane - orank;                       // lanes without a leaf before this one
         // tab: the lanes in the order "owners first": lane p of tab holds the id of the p-th owner, lane T + h the h-th helper
         const int pos = owner ? orank : T + hrank;
         const int tab = __builtin_amdgcn_ds_permute(pos << 2, lane);
-        const bool helper = !owner && hrank < T;
-        const bool helped = owner && orank < H;
+        const unsigned long long helperLanes = ~om & __ballot(hrank < T), helpedLanes = om & __ballot(orank < H);
+        const bool helper = __builtin_amdgcn_inverse_ballot_w64(helperLanes);
         const int partner = __builtin_amdgcn_ds_bpermute((owner ? T + orank : hrank) << 2, tab);
         const int src = helper ? partner : lane;
         F3 po = f3(shfl_f(src, o.x), shfl_f(src, o.y), shfl_f(src, o.z)), pd = f3(shfl_f(src, d.x), shfl_f(src, d.y), shfl_f(src, d.z));
         const uint32_t pcur = shfl_u(src, cur);
         uint32_t slot = pcur - leafBase + (helper ? 1u : 0u);
-        slot = slot < numLeaf ? slot : numLeaf - 1;             // a helper's triangle may lie beyond the owner's leaf, even beyond the array
-        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-        uint32_t upper = LANE_FINISHED, lower = LANE_FINISHED;
-        if (owner | helper) {
-            const float4* tr = S.tris + (size_t)slot * MIPT_TRI_F4;
+        slot = min(slot, numLeaf - 1);                           // a helper's triangle may lie beyond the owner's leaf, even beyond the array
+        // the record and the stack rows of a lane that takes no part are never looked at: their registers stay as they are
+        float4 a, b, c;
+        uint32_t upper, lower;
+        asm("; not set" : "=v"(a.x), "=v"(a.y), "=v"(a.z), "=v"(a.w), "=v"(b.x), "=v"(b.y), "=v"(b.z), "=v"(b.w));
+        asm("; not set" : "=v"(c.x), "=v"(c.y), "=v"(c.z), "=v"(c.w), "=v"(upper), "=v"(lower));
+        if (__builtin_amdgcn_inverse_ballot_w64(om | helperLanes)) {
+            const float4* tr = (const float4*)((const char*)S.tris + slot * (uint32_t)(MIPT_TRI_F4 * sizeof(float4)));      // the builder keeps the array below 4 GiB
             a = tr[0]; b = tr[1]; c = tr[2];
         }
         if (owner) rows_below(lds, upper, lower);
@@ -433,29 +485,32 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         bool accept = ray_triangle_all(po, pd, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), eps, t, u, v);
         if (MODE != 0) accept = accept & (t < FLT_MAX);
         const int32_t id = (int32_t)__float_as_uint(a.w);
-        const bool last1 = (__float_as_uint(b.w) != 0) | (slot + 1 >= numLeaf);
-        // what the owner learns from its helper: (t, u, v) and the id with two flags above it
-        const uint32_t packed = ((uint32_t)id & 0x3fffffffu) | (accept ? 0x80000000u : 0u) | (last1 ? 0x40000000u : 0u);
-        const float ht = shfl_f(partner, t), hu = shfl_f(partner, u), hv = shfl_f(partner, v);
+        const uint32_t lastBits = __float_as_uint(b.w);         // 1 at the last triangle of a leaf (the last triangle of the array is one)
+        // what the owner learns from its helper: (t, u, v) with t = infinity for a triangle that was not accepted, and the id
+        // with the end-of-leaf flag above it
+        const uint32_t packed = (uint32_t)id | (lastBits << 30);
+        const float ht = shfl_f(partner, accept ? t : __builtin_inff()), hu = shfl_f(partner, u), hv = shfl_f(partner, v);
         const uint32_t hp = shfl_u(partner, packed);
-        const bool use2 = helped & !last1;
-        const bool acc2 = use2 & ((hp >> 31) != 0);
-        const bool last2 = (hp & 0x40000000u) != 0;
+        const unsigned long long lastLanes = __ballot(lastBits != 0);
+        const unsigned long long use2Lanes = helpedLanes & ~lastLanes;       // owners whose own triangle was not the last and who have a helper
+        const bool use2 = __builtin_amdgcn_inverse_ballot_w64(use2Lanes);
+        const bool last2 = hp >= 0x40000000u;
         const int32_t id2 = (int32_t)(hp & 0x3fffffffu);
-        triCount += (owner ? 1u : 0u) + (use2 ? 1u : 0u);
+        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %2" : "+v"(triCount) : "s"(om), "s"(use2Lanes) : "vcc");
         bool occluded = false;
         if (MODE != 0) {
+            const bool acc2 = use2 & (ht < __builtin_inff());
             occluded = owner & (accept | acc2);
             best.tri = (owner & accept) ? id : ((owner & acc2) ? id2 : best.tri);
         } else {
             bool better = owner & accept & ((t < best.t) | ((t == best.t) & (id < best.tri)));
             best.t = better ? t : best.t; best.u = better ? u : best.u; best.v = better ? v : best.v; best.tri = better ? id : best.tri;
-            bool better2 = acc2 & ((ht < best.t) | ((ht == best.t) & (id2 < best.tri)));
+            bool better2 = use2 & ((ht < best.t) | ((ht == best.t) & (id2 < best.tri)));
             best.t = better2 ? ht : best.t; best.u = better2 ? hu : best.u; best.v = better2 ? hv : best.v; best.tri = better2 ? id2 : best.tri;
             tcull = (better | better2) ? best.t * 1.0000153f : tcull;
             cullEntry = __float_as_uint(tcull) | slotMask;
         }
-        const bool last = last1 | (use2 & last2);
+        const bool last = (lastBits != 0) | (use2 & last2);
         uint32_t old; int rows;
         take(upper, lower, old, rows);
         if (owner) {
@@ -463,6 +518,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
             uint32_t next = last ? (old & slotMask) : cur + (use2 ? 2u : 1u);
             cur = occluded ? LANE_FINISHED : next;
         }
+        ISA_MARK("triangle step end");
     };
 #endif
 
@@ -526,35 +582,86 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_PROFILE
             pNodePhases++;
 #endif
-            do {
+            // the common case first: a loop of steps whose stack rows all lie in LDS, left for the general loop as soon
+            // as a lane that is about to step could push beyond the LDS part (one step in 300 on the headline frame)
+            // (the two ballots are combined as masks: a ballot of the combined condition would cost three more instructions)
+            unsigned long long atNode = __ballot(at_node(cur));
+            auto deep_lanes = [&]() { return atNode & __ballot(sp + 3 >= ldsCap); };
+            if (__builtin_expect(deep_lanes() == 0, 1)) {
+                bool again;
+                do {
 #ifdef MIPT_TRACE_PROFILE
-                pNodeIters++;
+                    pNodeIters++;
 #endif
-                if (at_node(cur)) {
-                    const bool lds = __ballot(sp + 3 >= ldsCap) == 0;
+                    if (__builtin_amdgcn_inverse_ballot_w64(atNode)) node_step(true);
+                    atNode = __ballot(at_node(cur));
+                    // lanes at a node, or 0 if one of them is about to leave the LDS part: three scalar instructions
+                    // (written as C++ the condition is rebuilt from two 64-bit truth values and costs five more)
+                    int nodeLanes; unsigned long long deepNow;
+                    asm("s_bcnt1_i32_b64 %0, %2\n\ts_and_b64 %1, %2, %3\n\ts_cselect_b32 %0, 0, %0"
+                        : "=&s"(nodeLanes), "=&s"(deepNow) : "s"(atNode), "s"(__ballot(sp + 3 >= ldsCap)) : "scc");
+                    again = nodeLanes > stay;
+                } while (again);
+            }
+            const bool more = __popcll(atNode) > stay;
+            if (__builtin_expect(more, 0)) {
+                do {
 #ifdef MIPT_TRACE_PROFILE
-                    pSlow += !lds;
+                    pNodeIters++;
 #endif
-                    node_step(lds);
-                }
-            } while (__popcll(__ballot(at_node(cur))) > stay);
+                    if (at_node(cur)) {
+                        const bool lds = __ballot(sp + 3 >= ldsCap) == 0;
+#ifdef MIPT_TRACE_PROFILE
+                        pSlow += !lds;
+#endif
+                        node_step(lds);
+                    }
+                } while (__popcll(__ballot(at_node(cur))) > stay);
+            }
         };
         // ---- triangle steps
         auto triPhase = [&]() {
             // further triangle steps follow at once while enough of the lanes that entered are still at a leaf
-            const int triKeep = (__popcll(triMask) * triStay) >> 3;
+            const int triKeep = triStay > 0 ? (__popcll(triMask) * triStay) >> 3 : WAVE;      // triStay 0: one step
+#ifndef MIPT_NO_COOP_LEAF
+            // as in the node phase: a loop for the common case (the rows the owners read lie in LDS), left for the general one
+            unsigned long long atLeaf = triMask;
+            auto deep_lanes = [&]() { return atLeaf & __ballot(sp > ldsCap); };
+            bool first = true;
+            if (__builtin_expect(deep_lanes() == 0, 1)) {
+                bool again;
+                do {
+#ifdef MIPT_TRACE_PROFILE
+                    pTriIters++;
+#endif
+                    tri_step_coop(true, atLeaf);
+                    first = false;
+                    atLeaf = __ballot(at_leaf(cur));
+                    int leafLanes; unsigned long long deepNow;
+                    asm("s_bcnt1_i32_b64 %0, %2\n\ts_and_b64 %1, %2, %3\n\ts_cselect_b32 %0, 0, %0"
+                        : "=&s"(leafLanes), "=&s"(deepNow) : "s"(atLeaf), "s"(__ballot(sp > ldsCap)) : "scc");
+                    again = leafLanes > triKeep;
+                } while (again);
+            }
+            if (__builtin_expect(first | (__popcll(atLeaf) > triKeep), 0)) {
+                do {
+#ifdef MIPT_TRACE_PROFILE
+                    pTriIters++;
+#endif
+                    atLeaf = __ballot(at_leaf(cur));
+                    tri_step_coop((atLeaf & __ballot(sp > ldsCap)) == 0, atLeaf);
+                } while (__popcll(__ballot(at_leaf(cur))) > triKeep);
+            }
+#else
             do {
 #ifdef MIPT_TRACE_PROFILE
                 pTriIters++;
 #endif
-#ifndef MIPT_NO_COOP_LEAF
-                tri_step_coop(__ballot(at_leaf(cur) && sp > ldsCap) == 0);
-#else
                 if (at_leaf(cur)) {
                     tri_step(__ballot(sp > ldsCap) == 0);
                 }
+            } while (__popcll(__ballot(at_leaf(cur))) > triKeep);
 #endif
-            } while (triStay > 0 && __popcll(__ballot(at_leaf(cur))) > triKeep);
         };
         // the triangle phase follows the node phase in the same round
         if (nodeMask != 0 && __popcll(triMask) < triVote) {
