@@ -323,6 +323,12 @@ int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt
     {
         uint64_t codes = (uint64_t)s->bvh.numNodeSlots + (uint64_t)s->bvh.numLeafSlots + 1;      // child codes are 0 .. codes - 2, codes - 1 marks the end of a stack
         if (codes >= (1ull << 30)) { mipt_scene_destroy(s); return fail(MIPT_E_LIMIT, "BVH too large"); }
+        // the traversal addresses node slots and triangle records by 32-bit byte offsets
+        const uint64_t slotLimit = (1ull << 32) / (16 * (MIPT_NODE_WIDTH > MIPT_TRI_F4 ? MIPT_NODE_WIDTH : MIPT_TRI_F4));
+        if ((uint64_t)s->bvh.numNodeSlots >= slotLimit || (uint64_t)s->bvh.numLeafSlots >= slotLimit) {
+            mipt_scene_destroy(s);
+            return fail(MIPT_E_LIMIT, "BVH too large: %lld node slots, %lld triangle records, limit %llu each", (long long)s->bvh.numNodeSlots, (long long)s->bvh.numLeafSlots, (unsigned long long)slotLimit - 1);
+        }
         uint32_t m = 1;
         while (m < codes) m <<= 1;
         D.slotMask = m - 1;

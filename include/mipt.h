@@ -201,7 +201,9 @@ int mipt_device_name(char* buf, int32_t buflen);
 
 /* Flattens the scene, uploads it once and builds the SAH BVH on the GPU.
  * Replaces the per-call deep copy of PathTracer.cu:593-677 (CopyMesh :466-499)
- * and the octree of Mesh.cpp:88-166. */
+ * and the octree of Mesh.cpp:88-166.
+ * MIPT_E_LIMIT when the tree would hold 2^26 or more node slots or triangle records (the traversal
+ * addresses both by 32-bit byte offsets; a scene of 50 million triangles is within the limit). */
 int mipt_scene_create(const mipt_scene_desc* desc, const mipt_build_options* opt, mipt_scene** out);
 void mipt_scene_destroy(mipt_scene* scene);
 int mipt_scene_get_info(const mipt_scene* scene, mipt_scene_info* out);
