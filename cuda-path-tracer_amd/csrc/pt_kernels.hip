@@ -571,10 +571,6 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
             }
         }
         unsigned long long triMask = __ballot(at_leaf(cur)), nodeMask = __ballot(at_node(cur));
-        if ((triMask | nodeMask) == 0 && __ballot(cur == LANE_FINISHED) == 0) {
-            if (queueDry && rangeNext >= rangeEnd) break;
-            continue;
-        }
         // ---- node steps, in a tight loop, until `nodeDrop` of the lanes that entered have left
         auto nodePhase = [&]() {
             int stay = __popcll(nodeMask) - nodeDrop;
@@ -690,6 +686,8 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
             write_result();
             cur = LANE_IDLE;
         }
+        // the wave is done when the queue has nothing more for it and every lane is idle
+        if (queueDry && rangeNext >= rangeEnd && __ballot(cur != LANE_IDLE) == 0) break;
     }
     unsigned long long rs = wave_sum_u32(rayCount), ns = wave_sum_u32(nodeCount), ts = wave_sum_u32(triCount);
 #ifdef MIPT_TRACE_PROFILE
