@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #endif
 
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
-    bool queueDry = false;
+    bool queueDry = false, firstReservation = true;
     // per-lane traversal state
     uint32_t cur = LANE_IDLE;
     int sp = 2, rayIdx = -1, tag0 = 0, tag1 = 0;
@@ -529,20 +529,25 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
         // ---- hand rays to idle lanes
         unsigned long long idleMask = __ballot(cur == LANE_IDLE);
         if (idleMask && !(queueDry && rangeNext >= rangeEnd) && (__popcll(idleMask) >= refillMin || __ballot(cur < LANE_FINISHED) == 0)) {
+            // A wave's first reservation is the chunk with the wave's own number, taken without an atomic (thousands of
+            // waves start at the same moment, and atomics on one address complete at about 90 per microsecond); the
+            // shared head counts the chunks behind those.
+            auto reserve = [&]() {
+                if (firstReservation) { firstReservation = false; return (int)waveId * chunk; }
+                int b = 0;
+                if (lane == 0) b = atomicAdd(head, chunk);
+                return __builtin_amdgcn_readfirstlane(b) + (int)(gridDim.x * (blockDim.x / WAVE)) * chunk;
+            };
             if (!BLOCKS) {
                 if (rangeNext >= rangeEnd) {
-                    int b = 0;
-                    if (lane == 0) b = atomicAdd(head, chunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
+                    int b = reserve();
                     if ((uint32_t)b >= (uint32_t)n) queueDry = true;      // the head runs past n by up to one chunk per wave and may wrap: compared unsigned
                     else { rangeNext = b; rangeEnd = (b + chunk < n) ? b + chunk : n; }
                 }
             } else {
                 // a reservation in a queue in blocks can be without a valid entry: a few more are tried at once
                 for (int tries = 0; tries < 4 && rangeNext >= rangeEnd && !queueDry; tries++) {
-                    int b = 0;
-                    if (lane == 0) b = atomicAdd(head, chunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
+                    int b = reserve();
                     if ((uint32_t)b >= (uint32_t)n) { queueDry = true; break; }
                     int end = ((b >> MIPT_QBLOCK_SHIFT) << MIPT_QBLOCK_SHIFT) + blockCount[b >> MIPT_QBLOCK_SHIFT];
                     rangeNext = b; rangeEnd = (b + chunk < end) ? b + chunk : end;
