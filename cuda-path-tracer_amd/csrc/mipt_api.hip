@@ -715,6 +715,10 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7],
                 h[ST_PROF + 1] ? (double)h[ST_CLOSEST_NODES] / (double)h[ST_PROF + 1] : 0.0, h[ST_PROF + 2] ? (double)h[ST_CLOSEST_TRIS] / (double)h[ST_PROF + 2] : 0.0);
 #endif
+#ifdef MIPT_TRACE_TAIL
+        fprintf(stderr, "trace tail (closest-hit launches of the bounce levels): %llu waves, alive %.4g ms each on average, of that %.4g ms after the queue ran dry\n",
+                (unsigned long long)h[ST_PROF + 14], h[ST_PROF + 14] ? 1e-5 * (double)h[ST_PROF + 12] / (double)h[ST_PROF + 14] : 0.0, h[ST_PROF + 14] ? 1e-5 * (double)h[ST_PROF + 13] / (double)h[ST_PROF + 14] : 0.0);
+#endif
 #ifdef MIPT_TRACE_CLOCK
         fprintf(stderr, "trace clock (closest, summed over waves): node phases %.4g cycles (%.3f), triangle phases %.4g (%.3f), all %.4g\n",
                 (double)h[ST_PROF + 8], (double)h[ST_PROF + 8] / (double)h[ST_PROF + 10], (double)h[ST_PROF + 9], (double)h[ST_PROF + 9] / (double)h[ST_PROF + 10], (double)h[ST_PROF + 10]);

@@ -263,6 +263,11 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     unsigned long long cNode = 0, cTri = 0, cAll = __builtin_readcyclecounter();
 #endif
 
+#ifdef MIPT_TRACE_TAIL
+    // constant-rate clock (100 MHz) at the wave's start and at the moment the queue had nothing more for it
+    const unsigned long long wStart = wall_clock64();
+    unsigned long long wDry = 0;
+#endif
     int rangeNext = 0, rangeEnd = 0;        // rays reserved by this wave and not yet handed out
     bool queueDry = false, firstReservation = true;
     // per-lane traversal state
@@ -575,6 +580,9 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                 rangeNext += (want < avail) ? want : avail;
             }
         }
+#ifdef MIPT_TRACE_TAIL
+        if (wDry == 0 && queueDry && rangeNext >= rangeEnd) wDry = wall_clock64();
+#endif
         unsigned long long triMask = __ballot(at_leaf(cur)), nodeMask = __ballot(at_node(cur));
         // ---- node steps, in a tight loop, until `nodeDrop` of the lanes that entered have left
         auto nodePhase = [&]() {
@@ -706,6 +714,12 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_CLOCK
     if (lane == 0 && MODE == 0) {
         atomicAdd(&stats[ST_PROF + 8], cNode); atomicAdd(&stats[ST_PROF + 9], cTri); atomicAdd(&stats[ST_PROF + 10], __builtin_readcyclecounter() - cAll);
+    }
+#endif
+#ifdef MIPT_TRACE_TAIL
+    if (lane == 0 && MODE == 0 && BLOCKS == false && tagInHit) {      // the closest-hit launches of the bounce levels
+        const unsigned long long wExit = wall_clock64();
+        atomicAdd(&stats[ST_PROF + 12], wExit - wStart); atomicAdd(&stats[ST_PROF + 13], wExit - (wDry ? wDry : wExit)); atomicAdd(&stats[ST_PROF + 14], 1ull);
     }
 #endif
 #ifdef MIPT_ABLATE_LOAD
