@@ -596,8 +596,10 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
             // (the two ballots are combined as masks: a ballot of the combined condition would cost three more instructions)
             unsigned long long atNode = __ballot(at_node(cur));
             auto deep_lanes = [&]() { return atNode & __ballot(sp + 3 >= ldsCap); };
+            bool stepped = false;       // a phase is at least one step
             if (__builtin_expect(deep_lanes() == 0, 1)) {
                 bool again;
+                stepped = true;
                 do {
 #ifdef MIPT_TRACE_PROFILE
                     pNodeIters++;
@@ -612,7 +614,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                     again = nodeLanes > stay;
                 } while (again);
             }
-            const bool more = __popcll(atNode) > stay;
+            const bool more = !stepped | (__popcll(atNode) > stay);
             if (__builtin_expect(more, 0)) {
                 do {
 #ifdef MIPT_TRACE_PROFILE
