@@ -106,6 +106,22 @@ def measured_traffic(workload, kernel="k_trace<0>"):
         return None
 
 
+def traversal_roofs(tflops, traffic, launch_s):
+    """The two roofs of a traversal kernel and the one that names its bound: the larger share.
+    valu: algorithmic flop (box and triangle tests) over the kernel time against the FP32 vector peak.
+    hbm: the MEASURED fabric-side bytes of a launch (profiles/traffic.json, Infinity-Cache hits included) over its
+    duration against the HBM peak.  (The bytes the lanes ask for, 64 per node visit and 36 per triangle test, are
+    served by LDS, L1 and L2 at a rate above the HBM peak, so they say nothing about memory: requested_gbs.)
+    Without a measured traffic figure for the tree's kernel sources only the first roof is known."""
+    valu = {"achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS}
+    hbm = None
+    if traffic and launch_s > 0:
+        gbs = traffic / launch_s / 1e9
+        hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    first = ("hbm", hbm) if hbm and hbm["frac"] > valu["frac"] else ("valu", valu)
+    return {"bound": first[0], **first[1], "valu": valu, "hbm": hbm}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,10 +310,9 @@ def main():
                 "bvh_sah_cost": info.sah_cost, "bvh_node_width": width, "image_sha1": image_sha1, "samples_per_pass": int(s0.chunk_samples),
             },
             "roofline": {
-                # the larger of the two shares names the bound: FP32 vector peak or HBM peak
-                "kernel": "k_trace<0> (closest-hit BVH traversal)", "bound": "valu" if (hbm_frac or 0.0) <= valu_frac else "hbm",
-                "achieved": achieved_tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": valu_frac, "traffic": traffic,
+                "kernel": "k_trace<0> (closest-hit BVH traversal)",
+                **traversal_roofs(achieved_tf, traffic, closest_s / launches),
+                "traffic": traffic,
                 "traffic_unit": "bytes per launch, fabric side of L2 (profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": bytes_ / launches,
                 "avg_launch_ms": 1e3 * closest_s / launches, "launches": int(launches),
@@ -316,8 +331,8 @@ def main():
             },
         }
         result["roofline_kernels"] = [
-            {"kernel": "k_trace<1> (any-hit BVH traversal of the shadow rays)", "bound": "valu", "achieved": sh_tf,
-             "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sh_tf / FP32_VECTOR_PEAK_TFLOPS,
+            {"kernel": "k_trace<1> (any-hit BVH traversal of the shadow rays)",
+             **traversal_roofs(sh_tf, sh_traffic, shadow_s / sh_launches),
              "traffic": sh_traffic, "avg_launch_ms": 1e3 * shadow_s / sh_launches, "launches": int(sh_launches),
              "ms_per_step": 1e3 * shadow_s / args.steps, "box_tests_per_node_visit": shadow_boxes_per_visit,
              "triangle_tests_per_s": sh_tests / shadow_s if shadow_s > 0 else 0.0, "node_visits_per_s": sh_visits / shadow_s if shadow_s > 0 else 0.0,

@@ -25,7 +25,7 @@
 #define MIPT_TRI_F4 4      // 64-byte records: a record never straddles a 128-byte line
 #endif
 #ifndef MIPT_NODE_WIDTH
-#define MIPT_NODE_WIDTH 4      // children per node slot: 4 (64-byte slots) or 8 (128-byte slots: words 3k .. 3k+2 = box of child k, words 24 .. 31 = child codes)
+#define MIPT_NODE_WIDTH 4      // children per node slot.  The builder can also collapse to 8 (128-byte slots: words 3k .. 3k+2 = box of child k, words 24 .. 31 = child codes); the traversal kernel is written for 4 only
 #endif
 #define MIPT_NODE_U4 MIPT_NODE_WIDTH   // uint4 per node slot
 #define MIPT_STACK_LDS_MAX 16   // stack rows (4 bytes per lane) kept in LDS (4 KiB per wave), the two bottom rows that mark the end of every lane's stack included; deeper rows, which one node step in two hundred needs, go to the spill slice

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds a variant of the HIP library with extra compiler flags into profiles/ab/<name>.so (for ab_libs.sh).
-# usage: bash profiles/build_variant.sh <name> "<flags>"     e.g.  valu32 "-DMIPT_ABLATE_VALU=32"
+# usage: bash profiles/build_variant.sh <name> "<flags>"     e.g.  abl_cvt "-DMIPT_ABLATE_CVT"
 set -eu
 cd "$(dirname "$0")/../cuda-path-tracer_amd"
 mkdir -p ../profiles/ab

@@ -7,12 +7,13 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r02_b_bench_line.json")
-STATS = os.path.join(ROOT, "profiles", "r02_b_bench_kernel_stats.csv")
+LINE = os.path.join(ROOT, "profiles", "r03_b_bench_line.json")
+LINE_PROFILED = os.path.join(ROOT, "profiles", "r03_b_bench_line_under_rocprof.json")      # printed while rocprofv3 made STATS
+STATS = os.path.join(ROOT, "profiles", "r03_b_bench_kernel_stats.csv")
 
 
-def load_line():
-    with open(LINE) as f:
+def load_line(path=LINE):
+    with open(path) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -37,13 +38,32 @@ def test_bench_line_numbers_hang_together():
     assert c["reference_rays_per_frame"] == pytest.approx(c["rays_per_frame"] + c["shadow_rays_not_traversed_per_frame"])
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     assert 2.0 <= r["box_tests_per_node_visit"] <= c["bvh_node_width"]
-    # the HBM fraction is the measured fabric-side traffic of a launch over its duration, against the peak
+    # both roofs are reported; the one with the larger share names the bound and fills achieved / peak / unit / frac
+    valu, hbm = r["valu"], r["hbm"]
+    assert valu["unit"] == "TFLOP/s" and valu["frac"] == pytest.approx(valu["achieved"] / valu["peak"], rel=1e-9)
+    assert hbm is not None, "the committed line was measured with the traffic figure of its own kernel sources"
+    assert hbm["unit"] == "GB/s" and hbm["frac"] == pytest.approx(hbm["achieved"] / hbm["peak"], rel=1e-9)
+    first = hbm if hbm["frac"] > valu["frac"] else valu
+    assert r["bound"] == ("hbm" if first is hbm else "valu")
+    assert (r["achieved"], r["peak"], r["unit"], r["frac"]) == (first["achieved"], first["peak"], first["unit"], first["frac"])
+    # the HBM share is the measured fabric-side traffic of a launch over its duration, against the peak
     assert r["hbm_frac"] == pytest.approx(r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["hbm_peak_gbs"], rel=1e-6)
+    assert hbm["frac"] == pytest.approx(r["hbm_frac"], rel=1e-6)
     assert 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # the tree is served from the caches
-    # the closest-hit kernel's launch time from HIP events agrees with the rocprofv3 summary of the same command
-    if not os.path.exists(STATS):
+    kinds = [k["kernel"].split()[0] for k in d["roofline_kernels"]]
+    assert kinds == ["k_trace<1>", "k_shade_bounce"]
+    for k in d["roofline_kernels"]:
+        assert k["frac"] == pytest.approx(k["achieved"] / k["peak"], rel=1e-9) and k["bound"] in ("valu", "hbm")
+
+
+def test_kernel_time_from_events_agrees_with_the_rocprofv3_summary():
+    """The closest-hit kernel's launch time from HIP events and from rocprofv3, both of the same run of the same command."""
+    if not (os.path.exists(STATS) and os.path.exists(LINE_PROFILED)):
         pytest.skip("the rocprofv3 summary does not travel to the GPU box")
+    r = load_line(LINE_PROFILED)["roofline"]
     with open(STATS) as f:
         rows = {row["kernel"]: row for row in csv.DictReader(f)}
     k2 = next(v for k, v in rows.items() if k.startswith("k_trace<0, false, false>"))      # the timed instance (the counting one runs once more)
     assert float(k2["average_us"]) / 1e3 == pytest.approx(r["avg_launch_ms"], rel=0.02)
+    # without the profiler attached the launches are a little shorter
+    assert load_line()["roofline"]["avg_launch_ms"] == pytest.approx(r["avg_launch_ms"], rel=0.06)
