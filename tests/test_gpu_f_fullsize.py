@@ -9,6 +9,8 @@ triangle edge.
  - primary-hit ids in the window: identical
  - GI values: mean within 3 sigma of the Monte Carlo error, RMSE printed, >= 90 % identical
  - direct light (no sampling involved): identical bit for bit over a whole row
+ - the 10-million-triangle scene of configuration 5 at 3840x2160: a direct-light window bit for bit, and a
+   short GI window (8 samples; 512 would keep the brute-force search busy for an hour)
 """
 import numpy as np
 import pytest
@@ -68,4 +70,40 @@ def test_direct_light_full_resolution_row_is_bit_exact(gpu):
     assert np.array_equal(img[row].view(np.uint32), oimg[row].view(np.uint32))
     assert np.array_equal(host.pack_bgra(img)[row * WIDTH:(row + 1) * WIDTH].reshape(-1), odw[row])
     assert st.closest_rays == WIDTH * HEIGHT
+    sc.close()
+
+
+def test_ten_million_triangles_at_2160p_windows_against_brute_force(gpu):
+    """Configuration 5: 38 shifted copies of the 262 k-triangle scene as one triangle list, 3840x2160."""
+    import time
+    t0 = time.time()
+    scene = host.HostScene.atrium(abi.SCENE_CRYTEK, 262000, 256, 1).instanced(38, 4000.0)
+    W, H = 3840, 2160
+    cam, sun = host.camera_preset(abi.SCENE_CRYTEK, W, H, 1)
+    sc = gpu.Scene(scene.desc)
+    assert sc.info().num_triangles > 9_900_000
+    osc = ob.OracleScene(scene.desc)
+    t1 = time.time()
+    # direct light: 1024 pixels of one row, bit for bit
+    prm = host.default_params(sun_pos=sun, global_illumination=0, num_samples=512, use_textures=1, use_normals=0)
+    img, ids, st = sc.render(cam, prm)
+    row, cols = 1200, (1408, 2432)
+    oimg, odw, otri, ost = osc.render(cam, prm, accel=ob.ACCEL_BRUTE, row_step=H, row_phase=row, cols=cols)
+    win = slice(cols[0], cols[1])
+    assert np.array_equal(ids[row, win], otri[row, win])
+    assert (otri[row, win] >= 0).mean() > 0.9
+    assert np.array_equal(img[row, win].view(np.uint32), oimg[row, win].view(np.uint32))
+    assert st.closest_rays == W * H
+    t2 = time.time()
+    # global illumination, 8 samples: 32 pixels of the same row
+    prm = host.default_params(sun_pos=sun, global_illumination=1, num_samples=8, use_textures=1, use_normals=0)
+    img, ids, st = sc.render(cam, prm)
+    cols = (1900, 1932)
+    oimg, _, otri, ost = osc.render(cam, prm, accel=ob.ACCEL_BRUTE, row_step=H, row_phase=row, cols=cols)
+    win = slice(cols[0], cols[1])
+    assert np.array_equal(ids[row, win], otri[row, win])
+    rmse, dmean, sigma, same = window_compare(img[row, win], oimg[row, win])
+    print(f"9.96 M triangles, 2160p: scenes {t1 - t0:.1f} s, direct window {t2 - t1:.1f} s, GI window {time.time() - t2:.1f} s "
+          f"({ost.closest_rays + ost.shadow_rays} rays, {ost.triangle_tests:.3g} triangle tests): rmse={rmse:.4g} |dmean|={dmean:.4g} sigma={sigma:.4g} identical={same:.4f}")
+    assert same >= 0.85 and dmean <= 3 * sigma + 1e-6
     sc.close()
