@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
     // half of all node visits go), then one stack area per wave.  The waves of a workgroup share the
     // node copy and nothing else: after the copy is made they never meet again.
     extern __shared__ uint4 smem4[];
-    const int lane = threadIdx.x & (WAVE - 1), waveInGroup = threadIdx.x / WAVE;
+    // (the wave's number is the same in all its lanes: said explicitly, so that what is derived from it stays in scalar registers)
+    const int lane = threadIdx.x & (WAVE - 1), waveInGroup = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int ldsCap = S.stackLds;
     const uint4* __restrict__ nodes = S.nodes;
     const uint32_t leafBase = S.leafBase, slotMask = S.slotMask, numLeaf = (uint32_t)S.numTris;
@@ -583,7 +584,13 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_TAIL
         if (wDry == 0 && queueDry && rangeNext >= rangeEnd) wDry = wall_clock64();
 #endif
-        unsigned long long triMask = __ballot(at_leaf(cur)), nodeMask = __ballot(at_node(cur));
+        // where the lanes are: one subtraction, two compares (codes are below 2^30: a node's code minus leafBase is negative)
+        auto lane_masks = [&](unsigned long long& leafLanes, unsigned long long& nodeLanes) {
+            const uint32_t rel = cur - leafBase;
+            leafLanes = __ballot(rel < numLeaf); nodeLanes = __ballot((int32_t)rel < 0);
+        };
+        unsigned long long triMask, nodeMask;
+        lane_masks(triMask, nodeMask);
         // ---- node steps, in a tight loop, until `nodeDrop` of the lanes that entered have left
         auto nodePhase = [&]() {
             int stay = __popcll(nodeMask) - nodeDrop;
@@ -614,8 +621,8 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                     again = nodeLanes > stay;
                 } while (again);
             }
-            const bool more = !stepped | (__popcll(atNode) > stay);
-            if (__builtin_expect(more, 0)) {
+            const int left = stepped ? __popcll(atNode) : WAVE + 1;      // lanes still at a node; "all of them" if no step was taken yet
+            if (__builtin_expect(left > stay, 0)) {
                 do {
 #ifdef MIPT_TRACE_PROFILE
                     pNodeIters++;
@@ -654,7 +661,8 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                     again = leafLanes > triKeep;
                 } while (again);
             }
-            if (__builtin_expect(first | (__popcll(atLeaf) > triKeep), 0)) {
+            const int left = first ? WAVE + 1 : __popcll(atLeaf);
+            if (__builtin_expect(left > triKeep, 0)) {
                 do {
 #ifdef MIPT_TRACE_PROFILE
                     pTriIters++;
@@ -683,7 +691,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #ifdef MIPT_TRACE_CLOCK
             cNode += __builtin_readcyclecounter() - c0;
 #endif
-            triMask = __ballot(at_leaf(cur)); nodeMask = __ballot(at_node(cur));
+            lane_masks(triMask, nodeMask);
         }
         if (triMask != 0 && (nodeMask == 0 || __popcll(triMask) >= triVote)) {
 #ifdef MIPT_TRACE_CLOCK
