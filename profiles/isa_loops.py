@@ -1,6 +1,6 @@
 """Cuts the two traversal steps out of the compiled closest-hit kernel and counts their instructions.
 
-    python profiles/isa_loops.py profiles/r03_k_trace
+    python profiles/isa_loops.py profiles/r03_k_trace [more compiler flags, e.g. -DMIPT_PK_FMA]
 
 compiles csrc/pt_kernels.hip to assembly with -DMIPT_ISA_MARKERS (the steps are then bracketed by comments) and
 writes <prefix>_node_step.s and <prefix>_tri_step.s: the inner loop of k_trace<0, false, false> that holds the marker,
@@ -65,10 +65,10 @@ def straight_path(blocks, header):
             return path
 
 
-def main(prefix):
+def main(prefix, extra_flags=()):
     src = os.path.join(ROOT, "cuda-path-tracer_amd", "csrc", "pt_kernels.hip")
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-                          "-fno-slp-vectorize", "-Wno-unused-function", "-DMIPT_ISA_MARKERS", "--cuda-device-only", "-S", "-o", "-", src],
+                          "-fno-slp-vectorize", "-Wno-unused-function", "-DMIPT_ISA_MARKERS", *extra_flags, "--cuda-device-only", "-S", "-o", "-", src],
                          capture_output=True, text=True, check=True).stdout.split("\n")
     start = next(i for i, l in enumerate(asm) if l.startswith("_Z7k_traceILi0ELb0ELb0E"))
     end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
@@ -100,4 +100,4 @@ def main(prefix):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2:])
