@@ -2,7 +2,7 @@
 instead of the BVH) must give the image the BVH search gives, bit for bit, wherever the sun stands;
 where no view can be built (sun inside the scene's box) the BVH answers and the result is the same.
 
-This file belongs to the experiment build of round 2 (profiles/r02_sun_view_experiment.md), which compiled
+This file belongs to an experiment build (profiles/r02_sun_view_experiment.md describes it), which compiled
 experiments/sun_view.hip into the library and added fields to mipt_params and mipt_stats for it.  The experiment
 was slower than the BVH search and is not in the library: the fields this test sets do not exist in the shipped
 headers, so the test is kept as a record and is not collected (it lives outside tests/)."""
