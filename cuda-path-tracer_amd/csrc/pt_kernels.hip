@@ -121,8 +121,9 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 // half-wave hits its own bank; rows beyond the LDS part, which only very deep trees need, live in
 // a per-wave slice of global memory).  TRACE_WAVES waves form a workgroup that shares a copy of the
 // first TRACE_CACHE_SLOTS node slots (the top of the tree) in LDS and nothing else.  Waves are
-// persistent: a wave reserves TRACE_CHUNK consecutive rays of the queue with one atomic and hands
-// them to its lanes as soon as they fall idle.  The queue is either dense (entries 0 .. count-1) or
+// persistent: a wave reserves TRACE_CHUNK consecutive rays of the queue with one atomic (its first
+// reservation is the chunk with the wave's own number and needs none) and hands them to its lanes as
+// soon as they fall idle.  The queue is either dense (entries 0 .. count-1) or
 // in blocks of 1 << MIPT_QBLOCK_SHIFT entries of which the first blockCount[b] are valid (the
 // shadow rays of bounce shading, which writes them without any atomic); a reservation never
 // straddles a block.
@@ -145,9 +146,12 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 //     the box first; see box_entry), stores the three farthest unconditionally and goes on with the
 //     nearest child that was hit, which never passes through the stack.  Only when no child was
 //     hit the next node is one of the two rows fetched ahead.
-//   * A triangle step fetches one 64-byte triangle record and the same two stack rows, runs the
-//     exact ray/triangle test including its division on every lane, and, if the triangle was the
-//     last of its leaf, goes on with one of the two rows.
+//   * A triangle step is run by all lanes of the wave.  A lane at a leaf ("owner") fetches one 64-byte
+//     triangle record and the same two stack rows and runs the exact ray/triangle test including its
+//     division; the k-th lane that is not at a leaf tests the NEXT triangle of the k-th owner's leaf with
+//     the owner's ray (handed over through ds_bpermute) and hands the result back.  The owner merges
+//     both (closest hit: smaller t, then lower id), moves on by two triangles and, past the last
+//     triangle of its leaf, goes on with one of the two rows.
 // Taking an entry off the stack looks at two rows and never more: the upper one unless its box
 // lies beyond the best hit found since it was pushed (then it is dropped), else the lower one,
 // whether that one is beyond the best hit or not - visiting a box beyond the best hit is wasted
@@ -841,6 +845,11 @@ template <typename K> static void allow_large_lds(K kernel)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return;
     if (done.load(std::memory_order_acquire) & (1u << dev)) return;
+    // the kernel takes a node's byte offset in the tree for its LDS address in the copy: the copy must be the kernel's
+    // only LDS object (the kernel checks the address itself and stops if it is not 0; here the cause is named)
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes != 0)
+        fprintf(stderr, "mipt: the traversal kernel was built with %zu bytes of static LDS in front of its node copy; its launches will stop\n", (size_t)fa.sharedSizeBytes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess)      // the launch that follows fails with a launch error whose cause would otherwise be invisible
         fprintf(stderr, "mipt: the traversal kernel was refused its LDS size (hipFuncSetAttribute: %s); its launches will fail\n", hipGetErrorString(e));
