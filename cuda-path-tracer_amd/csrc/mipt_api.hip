@@ -81,6 +81,9 @@ struct mipt_frame {
     int32_t* counters = nullptr; int32_t numCounters = 0;
     unsigned long long* stats = nullptr;
     std::vector<hipEvent_t> events;
+    // with own_pixels_only: the pixels of this shard's tiles, ascending (made when the shard fields change)
+    int32_t* ownPix = nullptr; int32_t numOwn = 0;
+    int32_t ownRank = -1, ownCount = -1, ownTile = -1;
     int32_t lastActive = 0;
     int32_t samplesDone = 0;                  // first-bounce samples summed into d_accum by the last accumulate call
     std::atomic<int> cancel{ 0 };
@@ -494,10 +497,40 @@ static int fill_render(mipt_frame* f, const mipt_camera* cam, const mipt_params*
     return MIPT_OK;
 }
 
+// With own_pixels_only the primary rays, their hits and their shading run over the pixels of this shard's tiles
+// alone.  The list of those pixels is made when the shard fields change; the pixels of the other shards are set
+// to "no hit" then, once, since nothing writes them afterwards.
+static int update_own_pixels(mipt_frame* f)
+{
+    DevRender& R = f->R;
+    R.ownPix = nullptr; R.numOwn = 0;
+    if (!R.ownPixelsOnly) { f->ownRank = f->ownCount = f->ownTile = -1; return MIPT_OK; }
+    if (f->ownRank != R.shardRank || f->ownCount != R.shardCount || f->ownTile != R.tileSize || !f->ownPix) {
+        std::vector<int32_t> own;
+        own.reserve((size_t)f->P / (size_t)R.shardCount + (size_t)R.tileSize * R.tileSize);
+        for (int32_t y = 0; y < R.H; y++) {
+            const int32_t tileRow = (y / R.tileSize) * R.tilesX;
+            for (int32_t tx = 0; tx < R.tilesX; tx++) {
+                if ((tileRow + tx) % R.shardCount != R.shardRank) continue;
+                const int32_t x0 = tx * R.tileSize, x1 = x0 + R.tileSize < R.W ? x0 + R.tileSize : R.W;
+                for (int32_t x = x0; x < x1; x++) own.push_back(y * R.W + x);
+            }
+        }
+        if (!f->ownPix) HIPTRY(hipMalloc(&f->ownPix, 4 * (size_t)f->P));
+        if (!own.empty()) HIPTRY(hipMemcpy(f->ownPix, own.data(), 4 * own.size(), hipMemcpyHostToDevice));
+        HIPTRY(hipMemset(f->pixState, 0, 64 * (size_t)f->P));
+        HIPTRY(hipMemset(f->triId, 0xff, 4 * (size_t)f->P));
+        f->numOwn = (int32_t)own.size();
+        f->ownRank = R.shardRank; f->ownCount = R.shardCount; f->ownTile = R.tileSize;
+    }
+    R.ownPix = f->ownPix; R.numOwn = f->numOwn;
+    return MIPT_OK;
+}
+
 void mipt_frame_destroy(mipt_frame* f)
 {
     if (!f) return;
-    void* ptrs[] = { f->primQ.o, f->primQ.d, f->primHit, f->pixState, f->triId, f->actPix, f->pixAccum, f->primShadowQ.o, f->primShadowQ.d,
+    void* ptrs[] = { f->ownPix, f->primQ.o, f->primQ.d, f->primHit, f->pixState, f->triId, f->actPix, f->pixAccum, f->primShadowQ.o, f->primShadowQ.d,
                      f->q[0].o, f->q[0].d, f->q[1].o, f->q[1].d, f->shadowQ.o, f->shadowQ.d, f->shadowBlocks, f->hit, f->pathState, f->counters, f->stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : f->events) (void)hipEventDestroy(e);
@@ -566,6 +599,8 @@ int mipt_frame_create(mipt_scene* s, const mipt_camera* cam, const mipt_params* 
     FRTRY(hipMalloc(&f->stats, 8 * ST_COUNT));
     f->events.resize(2 + 2 * (size_t)(2 + passes * 9));
     for (auto& e : f->events) { e = nullptr; FRTRY(hipEventCreate(&e)); }
+    rc = update_own_pixels(f);
+    if (rc) { mipt_frame_destroy(f); return rc; }
     *out = f;
     return MIPT_OK;
 }
@@ -582,8 +617,8 @@ int mipt_frame_set_params(mipt_frame* f, const mipt_camera* cam, const mipt_para
     // values are checked on a copy: a rejected call leaves the frame as it was
     const DevRender keepR = f->R;
     int rc = fill_render(f, cam, p);
-    if (rc) f->R = keepR;
-    return rc;
+    if (rc) { f->R = keepR; return rc; }
+    return update_own_pixels(f);
 }
 
 int64_t mipt_frame_num_pixels(const mipt_frame* f) { return f ? f->P : 0; }
@@ -610,12 +645,13 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
     HIPTRY(hipMemsetAsync(f->counters, 0, 4 * (size_t)f->numCounters, st));
     HIPTRY(hipMemsetAsync(f->stats, 0, 8 * ST_COUNT, st));
     HIPTRY(hipMemsetAsync(d_accum, 0, 12 * (size_t)P, st));
-    launch_set_i32(f->counters + 0, P, st);
+    const int32_t nPrimary = R.ownPix ? R.numOwn : P;        // primary rays: one per pixel, or one per pixel of this shard's tiles
+    launch_set_i32(f->counters + 0, nPrimary, st);
 
     // depth 0: primary rays, their surfaces and shadow rays
     launch_raygen(R, f->primQ, st);
     spanBegin(0);
-    launch_closest(S, f->primQ, f->counters + 0, P, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st, false, R.countBoxTests != 0);
+    launch_closest(S, f->primQ, f->counters + 0, nPrimary, f->counters + 1, f->primHit, R.eps, f->stats, g_numCUs, st, false, R.countBoxTests != 0);
     spanEnd();
     launch_shade_primary(S, R, f->primHit, f->pixState, f->triId, f->primShadowQ, f->counters + 2, f->actPix, f->counters + 4, f->stats, st);
     spanBegin(1);
@@ -698,18 +734,6 @@ int mipt_frame_accumulate(mipt_frame* f, float* d_accum, mipt_stats* stats, mipt
         HIPTRY(hipMemcpy(h, f->stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->closest_rays = h[ST_CLOSEST_RAYS]; stats->shadow_rays = h[ST_SHADOW_RAYS]; stats->shadow_rays_culled = h[ST_SHADOW_CULLED]; stats->closest_box_tests = h[ST_CLOSEST_BOXES];
         stats->shadow_box_tests = h[ST_SHADOW_BOXES]; stats->shaded_hits = h[ST_SHADE_HITS]; stats->bounce_rays_written = h[ST_SHADE_NEXT];
-        if (R.ownPixelsOnly) {
-            // the stand-in rays of pixels that belong to other shards are no rays of the image: not counted
-            int64_t owned = 0;
-            const int tilesY = (R.H + R.tileSize - 1) / R.tileSize;
-            for (int ty = 0; ty < tilesY; ty++)
-                for (int tx = 0; tx < R.tilesX; tx++)
-                    if ((ty * R.tilesX + tx) % R.shardCount == R.shardRank) {
-                        int w = R.W - tx * R.tileSize, hgt = R.H - ty * R.tileSize;
-                        owned += (int64_t)(w < R.tileSize ? w : R.tileSize) * (hgt < R.tileSize ? hgt : R.tileSize);
-                    }
-            stats->closest_rays -= (uint64_t)((int64_t)P - owned);
-        }
 #ifdef MIPT_TRACE_PROFILE
         fprintf(stderr, "trace profile (closest): rays %llu nodeVisits %llu triTests %llu | wave: outer %llu nodeIters %llu triIters %llu nodePhases %llu refills %llu finishEvents %llu finishLanes %llu slowNodeSteps %llu | lanes per node step %.1f per triangle step %.1f\n",
                 h[ST_CLOSEST_RAYS], h[ST_CLOSEST_NODES], h[ST_CLOSEST_TRIS], h[ST_PROF], h[ST_PROF + 1], h[ST_PROF + 2], h[ST_PROF + 3], h[ST_PROF + 4], h[ST_PROF + 5], h[ST_PROF + 6], h[ST_PROF + 7],

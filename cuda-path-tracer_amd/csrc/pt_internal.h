@@ -80,7 +80,9 @@ struct DevRender {
     uint32_t seed;
     int32_t  numSamples;
     int32_t  shardRank, shardCount, tileSize, tilesX;
-    int32_t  ownPixelsOnly;   // primary rays of other shards' tiles are replaced by rays that miss the scene
+    int32_t  ownPixelsOnly;   // only the pixels of this shard's tiles are rendered
+    int32_t  numOwn;          // with ownPixelsOnly: number of those pixels
+    const int32_t* ownPix;    // with ownPixelsOnly: their indices in ascending order (primary ray i belongs to pixel ownPix[i]); else null: ray i = pixel i
     int32_t  countBoxTests;   // the closest-hit launches also count the child boxes of the nodes they visit
 };
 

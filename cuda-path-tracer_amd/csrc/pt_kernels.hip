@@ -45,17 +45,14 @@ __device__ __forceinline__ void store_stream(float4* p, float4 v)
 // normalises once; XMVector3TransformCoord/Normal evaluate ((z*r2 [+ r3]) + y*r1) + x*r0)
 __device__ __forceinline__ bool pixel_owned(const DevRender& R, int p);
 
+// Ray i of the primary queue belongs to pixel i, or, when only this shard's pixels are rendered, to pixel ownPix[i].
+__device__ __forceinline__ int primary_count(const DevRender& R) { return R.ownPix ? R.numOwn : R.W * R.H; }
+
 __global__ void __launch_bounds__(256) k_raygen(DevRender R, RayQueue q)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= R.W * R.H) return;
-    if (R.ownPixelsOnly && !pixel_owned(R, p)) {
-        // a pixel of another shard: a ray from far outside that points away misses the root box at once,
-        // the pixel is then shaded as a miss (black, id -1) and starts no paths
-        q.o[p] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(p));
-        q.d[p] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        return;
-    }
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= primary_count(R)) return;
+    const int p = R.ownPix ? R.ownPix[i] : i;
     int j = p % R.W, h = p / R.W;
     const float* m = R.toLocal;
     float vx = (+2.0f * (float)R.div * j / (float)R.clientW - 1.0f) / R.p0;
@@ -69,13 +66,13 @@ __global__ void __launch_bounds__(256) k_raygen(DevRender R, RayQueue q)
     dir.y = (1.0f * m[9] + vy * m[5]) + vx * m[1];
     dir.z = (1.0f * m[10] + vy * m[6]) + vx * m[2];
     dir = f3normalize(dir);
-    q.o[p] = make_float4(r0 / r3, r1 / r3, r2 / r3, __int_as_float(p));
-    q.d[p] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    q.o[i] = make_float4(r0 / r3, r1 / r3, r2 / r3, __int_as_float(p));
+    q.d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
 }
 
 void launch_raygen(const DevRender& R, RayQueue q, hipStream_t s)
 {
-    int n = R.W * R.H;
+    int n = R.ownPix ? R.numOwn : R.W * R.H;
     hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, s, R, q);
 }
 
@@ -1072,10 +1069,10 @@ __global__ void __launch_bounds__(256) k_shade_primary(DevScene S, DevRender R, 
                                                       int32_t* shadowCount, int32_t* actPix, int32_t* actCount,
                                                       unsigned long long* stats)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = R.W * R.H;
-    bool inRange = p < n;
-    float4 h = inRange ? hit[p] : make_float4(0, 0, 0, __int_as_float(-1));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inRange = i < primary_count(R);
+    const int p = (inRange && R.ownPix) ? R.ownPix[i] : i;      // the pixel of primary ray i
+    float4 h = inRange ? hit[i] : make_float4(0, 0, 0, __int_as_float(-1));
     int tri = __float_as_int(h.w);
     bool isHit = inRange && tri >= 0;
     F3 so = f3(0, 0, 0), sd = f3(0, 0, 0);
@@ -1109,7 +1106,7 @@ void launch_shade_primary(const DevScene& S, const DevRender& R, const float4* h
                           int32_t* triIdImage, RayQueue shadowQ, int32_t* d_shadowCount, int32_t* actPix,
                           int32_t* d_actCount, unsigned long long* d_stats, hipStream_t s)
 {
-    int n = R.W * R.H;
+    int n = R.ownPix ? R.numOwn : R.W * R.H;
     hipLaunchKernelGGL(k_shade_primary, dim3((n + 255) / 256), dim3(256), 0, s, S, R, hit, pixState, triIdImage, shadowQ,
                        d_shadowCount, actPix, d_actCount, d_stats);
 }

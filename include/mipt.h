@@ -119,7 +119,8 @@ typedef struct mipt_params {
     int32_t  sample_begin;           /* first-bounce samples [sample_begin, sample_end) are */
     int32_t  sample_end;             /* traced by this call; 0,0 = all num_samples */
     int32_t  chunk_samples;          /* samples per wavefront pass, 0 = automatic */
-    int32_t  own_pixels_only;        /* 1: with tile sharding, trace the primary rays of this shard's tiles only;
+    int32_t  own_pixels_only;        /* 1: with tile sharding, the primary rays, their hits and their shading run over
+                                        the pixels of this shard's tiles alone;
                                         pixels of other shards finalize to black (and -1 in the id image), so
                                         the FINAL images of the shards add up to the frame.  0: every shard
                                         traces depth 0 for the whole image (needed when the sums are reduced
