@@ -722,14 +722,16 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     HIPCHK(hipMemcpyAsync(&rootH, nodes, sizeof(BNode), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     {
-        // every box grows by 2^-15 of the largest coordinate magnitude of the scene
+        // every box grows by 1.5 * 2^-15 of the largest coordinate magnitude of the scene: 2^-15 for the rounding of the
+        // traversal's arithmetic against the exact triangle test, the rest for the half grid cell by which the box test
+        // may misplace a plane (pt_device.h: BoxRay)
         auto k2f = [](int32_t i) { int32_t j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; };
         for (int a = 0; a < 3; a++) {
             float lo = fabsf(k2f(rootH.bminI[a])), hi = fabsf(k2f(rootH.bmaxI[a]));
             if (lo > sceneAbs) sceneAbs = lo;
             if (hi > sceneAbs) sceneAbs = hi;
         }
-        pad = sceneAbs * (1.0f / 32768.0f);
+        pad = sceneAbs * (1.5f / 32768.0f);
         if (!(pad > 0.0f)) pad = 1e-30f;
         // the 16-bit grid spans the padded scene box; a flat axis still gets a positive cell
         for (int a = 0; a < 3; a++) {

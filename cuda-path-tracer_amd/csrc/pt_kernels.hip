@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
 #endif
         // What a group of the node step's own instructions costs: the same number of them once more, independent
         // of each other, on registers nothing reads.  (Taking them out would change the result; adding them does not.)
-#ifdef MIPT_ABLATE_ALIGNBIT      // the 12 near/far rotations of box_test
+#ifdef MIPT_ABLATE_ALIGNBIT      // the 12 near/far rotations of box_test (of its -DMIPT_ROTATE_PLANES form)
         {
             uint32_t x0, x1, x2, x3;
             asm volatile("v_alignbit_b32 %0, %4, %4, 16\n\tv_alignbit_b32 %1, %5, %5, 16\n\tv_alignbit_b32 %2, %6, %6, 16\n\tv_alignbit_b32 %3, %7, %7, 16\n\t"
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(1024) k_trace(DevScene S, RayQueue q, const in
                          : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w));
         }
 #endif
-#ifdef MIPT_ABLATE_CVT           // the 24 conversions of 16-bit planes to float
+#ifdef MIPT_ABLATE_CVT           // the 24 conversions of 16-bit planes to float (of the -DMIPT_ROTATE_PLANES form; the byte permutes that replaced them cost the same each)
         {
             float x0, x1, x2, x3;
             #pragma unroll
