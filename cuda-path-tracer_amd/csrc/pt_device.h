@@ -160,12 +160,16 @@ struct BoxRay { float ix, iy, iz, nx, ny, nz; uint32_t snx, sny, snz, sfx, sfy, 
 struct BoxRay { float ix, iy, iz, nx, ny, nz; uint32_t sx, sy, sz; };
 #endif
 
+#ifndef MIPT_DIR_FLOOR
+#define MIPT_DIR_FLOOR 1e-20f      /* smallest direction component the box test divides by */
+#endif
 __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
 {
     BoxRay r;
-    float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
-    float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
-    float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
+    const float floor_ = MIPT_DIR_FLOOR;
+    float dx = fabsf(d.x) < floor_ ? copysignf(floor_, d.x) : d.x;
+    float dy = fabsf(d.y) < floor_ ? copysignf(floor_, d.y) : d.y;
+    float dz = fabsf(d.z) < floor_ ? copysignf(floor_, d.z) : d.z;
     // one-ulp reciprocals: the boxes carry a margin of 2^-15 of the scene size for the rounding of this arithmetic
     float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
     r.nx = (S.qmin[0] - o.x) * ix; r.ny = (S.qmin[1] - o.y) * iy; r.nz = (S.qmin[2] - o.z) * iz;

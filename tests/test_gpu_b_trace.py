@@ -106,6 +106,43 @@ def test_rays_that_start_on_box_planes(gpu, atrium_small, atrium_small_oracle):
     assert (tri >= 0).mean() > 0.5
 
 
+def test_axis_parallel_rays_in_a_large_scene(gpu):
+    """Coordinates in the millions and rays along the axes, exactly and with components of 1e-19 ... 1e-38: the box
+    test replaces a direction component below 1e-20 and multiplies the grid's extent by the reciprocal, which has to
+    stay finite (a product that overflowed would turn a box the ray runs through into a miss)."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    tris = []
+    for i in range(40):           # small triangles scattered over +-3e6, facing every axis
+        c = rng.uniform(-3e6, 3e6, 3)
+        axis = i % 3
+        a, b = (axis + 1) % 3, (axis + 2) % 3
+        h = rng.uniform(1e3, 1e5)
+        p0, p1, p2 = c.copy(), c.copy(), c.copy()
+        p0[a] -= h; p0[b] -= h; p1[a] += h; p1[b] -= h; p2[b] += h
+        tris.append([p0, p1, p2])
+    desc, keep = scenes.scene_from_triangles(tris)
+    sc = gpu.Scene(C.pointer(desc))
+    osc = ob.OracleScene(C.pointer(desc))
+    t = np.asarray(tris, dtype=np.float32)
+    rays = []
+    for i in range(t.shape[0]):
+        axis = i % 3
+        target = t[i].mean(axis=0)
+        for sign in (-1.0, 1.0):
+            for tiny in (0.0, 1e-19, -1e-19, 1e-21, -1e-25, 1e-30, -1e-38):
+                d = np.zeros(3, dtype=np.float32)
+                d[axis] = sign
+                d[(axis + 1) % 3] = tiny
+                d[(axis + 2) % 3] = -tiny
+                o = target.copy()
+                o[axis] -= sign * 5e6          # starts outside the scene's box, runs through the triangle
+                rays.append(np.concatenate([o, d]))
+    rays = np.asarray(rays, dtype=np.float32)
+    tri = assert_trace_parity(sc, osc, rays)
+    assert (tri >= 0).mean() > 0.9
+
+
 def test_deep_tree_uses_the_stack_beyond_lds(gpu):
     """Nested shells of triangles whose sizes fall geometrically give a tall, thin tree; rays
     through the common centre enter every child box on the way down, so the per-lane stack grows
