@@ -722,16 +722,20 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
     HIPCHK(hipMemcpyAsync(&rootH, nodes, sizeof(BNode), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     {
-        // every box grows by 1.5 * 2^-15 of the largest coordinate magnitude of the scene: 2^-15 for the rounding of the
-        // traversal's arithmetic against the exact triangle test, the rest for the half grid cell by which the box test
-        // may misplace a plane (pt_device.h: BoxRay)
+        // Every box grows by 2^-20 of the largest coordinate magnitude of the scene before it is rounded outwards to the
+        // grid, which covers the rounding of the quantisation itself (a 32nd of a cell of the longest axis against the
+        // 2^-8 cells by which (v - qmin) / cell can be off).  The margin against the rounding of the traversal's box
+        // test and of the triangle test is not in the boxes: the traversal applies it per ray (pt_device.h: BoxRay).
+#ifndef MIPT_PAD_SCALE
+#define MIPT_PAD_SCALE (1.0f / 32.0f)
+#endif
         auto k2f = [](int32_t i) { int32_t j = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &j, 4); return f; };
         for (int a = 0; a < 3; a++) {
             float lo = fabsf(k2f(rootH.bminI[a])), hi = fabsf(k2f(rootH.bmaxI[a]));
             if (lo > sceneAbs) sceneAbs = lo;
             if (hi > sceneAbs) sceneAbs = hi;
         }
-        pad = sceneAbs * (1.5f / 32768.0f);
+        pad = sceneAbs * (MIPT_PAD_SCALE / 32768.0f);
         if (!(pad > 0.0f)) pad = 1e-30f;
         // the 16-bit grid spans the padded scene box; a flat axis still gets a positive cell
         for (int a = 0; a < 3; a++) {

@@ -139,30 +139,46 @@ __device__ __forceinline__ bool ray_triangle_all(F3 o, F3 d, F3 v0, F3 e1, F3 e2
 // ---------------------------------------------------------------------------------------
 // Ray prepared for the box test on the 16-bit grid: with box coordinate = qmin + q * qcell the
 // slab distance (coordinate - origin) / direction becomes q * (qcell / d) + (qmin - o) / d, one
-// fused multiply-add per plane.  A direction component below 1e-20 is replaced by 1e-20 with its sign: along such an axis
-// the ray does not leave a box's margin within 10^15 scene sizes, and the products stay finite for scenes up to 10^16 units.
-// Ray in the units of the node grid: a plane at grid coordinate q is crossed at t = q * i + n.  A node word holds
-// (min | max << 16) of one child on one axis.
+// fused multiply-add per plane: a plane at grid coordinate q is crossed at t = q * i + n.  A node word holds
+// (min | max << 16) of one child on one axis.  A direction component below 1e-20 is replaced by 1e-20 with its
+// sign: along such an axis the ray does not leave a box's margin within 10^15 scene sizes, and the products stay
+// finite for scenes up to 10^16 units.
+//
+// THE MARGIN.  The box test must never reject a box that holds a triangle the exact test accepts, although both
+// are computed in rounded fp32 arithmetic.  The node boxes are rounded outwards to the grid and carry next to no
+// margin of their own (bvh_build.hip); the margin is applied here, per ray and axis, as two constant terms: the
+// plane a ray meets first on an axis uses cn = c - m / |d|, the plane it meets last cf = c + m / |d|, which is
+// the slab test of the box grown by m on that axis.  m = MIPT_BOX_MARGIN_ULPS units in the last place of the
+// ray's reach (the largest distance from its origin to a face of the grid, plus the grid's extent: the magnitude of
+// every operand of both tests, whose rounding errors are a few of those units each), plus, for the permute decode,
+// 0.51 grid cells of the axis.  Costs nothing per node step (a plane's multiply-add takes cn or cf where it took c),
+// grows with the distance of a far-away origin as the errors do, and is a fifth of the fixed margin of 2^-15 of the
+// largest coordinate that the boxes carried before (10 M triangles in 38 instances: 12 % fewer triangle tests).
+#ifndef MIPT_BOX_MARGIN_ULPS
+#define MIPT_BOX_MARGIN_ULPS 32.0f
+#endif
+#ifndef MIPT_BOX_MARGIN_CELLS
+#define MIPT_BOX_MARGIN_CELLS 0.51f      /* permute decode: grid cells by which a plane's constant term may be off, and a little */
+#endif
+#ifndef MIPT_DIR_FLOOR
+#define MIPT_DIR_FLOOR 1e-20f      /* smallest direction component the box test divides by */
+#endif
 #ifndef MIPT_ROTATE_PLANES
 // A plane's 16 bits q are placed under the exponent of 128.0f with one v_perm_b32 (value 128 + q / 65536, exact), so
 // that no integer has to be converted: t = value * I + C with I = 65536 * i and C = n - 128 * I.  C is rounded at the
-// magnitude of 128 * I, which moves a plane by up to half a grid cell (2^-17 of the grid's extent); the boxes' margin
-// (bvh_build.hip: 1.5 * 2^-15 of the largest coordinate) covers it.  sn / sf are the permute selectors that pick the
-// half of a node word the ray meets first / last on an axis.
+// magnitude of 128 * I, which moves a plane by up to half a grid cell (2^-17 of the grid's extent): that half cell is
+// part of the margin.  sn / sf are the permute selectors that pick the half of a node word the ray meets first / last.
 // (-DMIPT_ROTATE_PLANES builds the decode this one replaced: s is 16 on an axis where the direction is negative and 0
 // elsewhere, rotating a word by s puts the plane the ray meets first into the low half, and both halves are converted
 // to float; 12 more vector instructions per node step, closest-hit kernel +1.7 %, any-hit kernel +2.5 %.)
-struct BoxRay { float ix, iy, iz, nx, ny, nz; uint32_t snx, sny, snz, sfx, sfy, sfz; };
+struct BoxRay { float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz; uint32_t snx, sny, snz, sfx, sfy, sfz; };
 #define PERM_SEL_LO 0x070c0100u     /* bytes 0, 1 of the word, 0x00, byte 3 of the constant */
 #define PERM_SEL_HI 0x070c0302u     /* bytes 2, 3 of the word, 0x00, byte 3 of the constant */
 #define PERM_EXP    0x43000000u     /* 128.0f */
 #else
-struct BoxRay { float ix, iy, iz, nx, ny, nz; uint32_t sx, sy, sz; };
+struct BoxRay { float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz; uint32_t sx, sy, sz; };
 #endif
 
-#ifndef MIPT_DIR_FLOOR
-#define MIPT_DIR_FLOOR 1e-20f      /* smallest direction component the box test divides by */
-#endif
 __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
 {
     BoxRay r;
@@ -170,39 +186,48 @@ __device__ __forceinline__ BoxRay make_box_ray(const DevScene& S, F3 o, F3 d)
     float dx = fabsf(d.x) < floor_ ? copysignf(floor_, d.x) : d.x;
     float dy = fabsf(d.y) < floor_ ? copysignf(floor_, d.y) : d.y;
     float dz = fabsf(d.z) < floor_ ? copysignf(floor_, d.z) : d.z;
-    // one-ulp reciprocals: the boxes carry a margin of 2^-15 of the scene size for the rounding of this arithmetic
+    // one-ulp reciprocals (the margin counts them in)
     float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
-    r.nx = (S.qmin[0] - o.x) * ix; r.ny = (S.qmin[1] - o.y) * iy; r.nz = (S.qmin[2] - o.z) * iz;
+    const float ox = S.qmin[0] - o.x, oy = S.qmin[1] - o.y, oz = S.qmin[2] - o.z;
+    float nx = ox * ix, ny = oy * iy, nz = oz * iz;
     r.ix = ix * S.qcell[0]; r.iy = iy * S.qcell[1]; r.iz = iz * S.qcell[2];
+    // the ray's reach: no operand of the box test or of the triangle test is larger
+    const float ex = 65535.0f * S.qcell[0], ey = 65535.0f * S.qcell[1], ez = 65535.0f * S.qcell[2];
+    const float reach = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + fmaxf(fmaxf(ex, ey), ez);
+    float mx = reach * (MIPT_BOX_MARGIN_ULPS * 1.1920929e-7f), my = mx, mz = mx;
 #ifndef MIPT_ROTATE_PLANES
     r.ix *= 65536.0f; r.iy *= 65536.0f; r.iz *= 65536.0f;
-    r.nx = __builtin_fmaf(-128.0f, r.ix, r.nx); r.ny = __builtin_fmaf(-128.0f, r.iy, r.ny); r.nz = __builtin_fmaf(-128.0f, r.iz, r.nz);
-    const bool mx = (int32_t)__float_as_uint(dx) < 0, my = (int32_t)__float_as_uint(dy) < 0, mz = (int32_t)__float_as_uint(dz) < 0;
-    r.snx = mx ? PERM_SEL_HI : PERM_SEL_LO; r.sfx = mx ? PERM_SEL_LO : PERM_SEL_HI;
-    r.sny = my ? PERM_SEL_HI : PERM_SEL_LO; r.sfy = my ? PERM_SEL_LO : PERM_SEL_HI;
-    r.snz = mz ? PERM_SEL_HI : PERM_SEL_LO; r.sfz = mz ? PERM_SEL_LO : PERM_SEL_HI;
+    nx = __builtin_fmaf(-128.0f, r.ix, nx); ny = __builtin_fmaf(-128.0f, r.iy, ny); nz = __builtin_fmaf(-128.0f, r.iz, nz);
+    mx = __builtin_fmaf(MIPT_BOX_MARGIN_CELLS, S.qcell[0], mx); my = __builtin_fmaf(MIPT_BOX_MARGIN_CELLS, S.qcell[1], my); mz = __builtin_fmaf(MIPT_BOX_MARGIN_CELLS, S.qcell[2], mz);
+    const bool gx = (int32_t)__float_as_uint(dx) < 0, gy = (int32_t)__float_as_uint(dy) < 0, gz = (int32_t)__float_as_uint(dz) < 0;
+    r.snx = gx ? PERM_SEL_HI : PERM_SEL_LO; r.sfx = gx ? PERM_SEL_LO : PERM_SEL_HI;
+    r.sny = gy ? PERM_SEL_HI : PERM_SEL_LO; r.sfy = gy ? PERM_SEL_LO : PERM_SEL_HI;
+    r.snz = gz ? PERM_SEL_HI : PERM_SEL_LO; r.sfz = gz ? PERM_SEL_LO : PERM_SEL_HI;
 #else
     r.sx = (__float_as_uint(dx) >> 31) << 4; r.sy = (__float_as_uint(dy) >> 31) << 4; r.sz = (__float_as_uint(dz) >> 31) << 4;
 #endif
+    const float tx = mx * fabsf(ix), ty = my * fabsf(iy), tz = mz * fabsf(iz);      // the margin as a distance along the ray
+    r.cnx = nx - tx; r.cny = ny - ty; r.cnz = nz - tz;
+    r.cfx = nx + tx; r.cfy = ny + ty; r.cfz = nz + tz;
     return r;
 }
 
 // Slab test against a box given as three node words; tnear, tfar = entry and exit distance.  Conservative by
-// construction of the node boxes, never exact.
+// the ray's margin, never exact.
 // CULL: the exit distance is also cut at tcull, the distance beyond which a box cannot matter (closest hit).
 template <bool CULL>
 __device__ __forceinline__ bool box_test(const BoxRay& r, uint32_t wx, uint32_t wy, uint32_t wz, float tcull, float& tnear, float& tfar)
 {
 #ifndef MIPT_ROTATE_PLANES
     auto plane = [](uint32_t w, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(PERM_EXP, w, sel)); };
-    float x0 = __builtin_fmaf(plane(wx, r.snx), r.ix, r.nx), x1 = __builtin_fmaf(plane(wx, r.sfx), r.ix, r.nx);
-    float y0 = __builtin_fmaf(plane(wy, r.sny), r.iy, r.ny), y1 = __builtin_fmaf(plane(wy, r.sfy), r.iy, r.ny);
-    float z0 = __builtin_fmaf(plane(wz, r.snz), r.iz, r.nz), z1 = __builtin_fmaf(plane(wz, r.sfz), r.iz, r.nz);
+    float x0 = __builtin_fmaf(plane(wx, r.snx), r.ix, r.cnx), x1 = __builtin_fmaf(plane(wx, r.sfx), r.ix, r.cfx);
+    float y0 = __builtin_fmaf(plane(wy, r.sny), r.iy, r.cny), y1 = __builtin_fmaf(plane(wy, r.sfy), r.iy, r.cfy);
+    float z0 = __builtin_fmaf(plane(wz, r.snz), r.iz, r.cnz), z1 = __builtin_fmaf(plane(wz, r.sfz), r.iz, r.cfz);
 #else
     uint32_t px = __builtin_amdgcn_alignbit(wx, wx, r.sx), py = __builtin_amdgcn_alignbit(wy, wy, r.sy), pz = __builtin_amdgcn_alignbit(wz, wz, r.sz);
-    float x0 = __builtin_fmaf((float)(px & 0xffffu), r.ix, r.nx), x1 = __builtin_fmaf((float)(px >> 16), r.ix, r.nx);
-    float y0 = __builtin_fmaf((float)(py & 0xffffu), r.iy, r.ny), y1 = __builtin_fmaf((float)(py >> 16), r.iy, r.ny);
-    float z0 = __builtin_fmaf((float)(pz & 0xffffu), r.iz, r.nz), z1 = __builtin_fmaf((float)(pz >> 16), r.iz, r.nz);
+    float x0 = __builtin_fmaf((float)(px & 0xffffu), r.ix, r.cnx), x1 = __builtin_fmaf((float)(px >> 16), r.ix, r.cfx);
+    float y0 = __builtin_fmaf((float)(py & 0xffffu), r.iy, r.cny), y1 = __builtin_fmaf((float)(py >> 16), r.iy, r.cfy);
+    float z0 = __builtin_fmaf((float)(pz & 0xffffu), r.iz, r.cnz), z1 = __builtin_fmaf((float)(pz >> 16), r.iz, r.cfz);
 #endif
     float tmin = fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f));
     float zc = z1;

@@ -143,6 +143,37 @@ def test_axis_parallel_rays_in_a_large_scene(gpu):
     assert (tri >= 0).mean() > 0.9
 
 
+def test_rays_from_far_outside_the_scene(gpu, atrium_small, atrium_small_oracle):
+    """Origins 3 to 300 scene sizes away, aimed at vertices, edge midpoints and interior points of triangles: the
+    rounding errors of the triangle test and of the box test grow with the distance, and so must the margin of the
+    box test (it is a number of units in the last place of the ray's reach; built without that part,
+    -DMIPT_BOX_MARGIN_ULPS=0, the search loses 95 of the 12 000 rays from 300 and 3000 scene sizes away).  From
+    3000 scene sizes away, where one unit in the last place of the origin is a 4000th of the scene and the triangle
+    test's own barycentric coordinates are off by 0.1, 3 of 6000 rays still differ from the brute-force search: not tested."""
+    rng = np.random.default_rng(41)
+    v = atrium_small.vertices()[:, :, :3]
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    size = float(np.linalg.norm(hi - lo))
+    rays = []
+    for dist in (3.0, 30.0, 300.0):
+        n = 6000
+        tri = v[rng.integers(0, v.shape[0], n)]
+        w = rng.random((n, 3)); w /= w.sum(axis=1, keepdims=True)
+        kind = rng.integers(0, 3, n)
+        target = np.einsum("nk,nkc->nc", w, tri)                                   # interior point
+        target = np.where((kind == 1)[:, None], tri[:, 0], target)                 # a vertex
+        target = np.where((kind == 2)[:, None], 0.5 * (tri[:, 0] + tri[:, 1]), target)   # an edge midpoint
+        dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        o = (target - dirs * dist * size).astype(np.float32)
+        d = target - o.astype(np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays.append(np.concatenate([o, d.astype(np.float32)], axis=1))
+    rays = np.concatenate(rays).astype(np.float32)
+    sc = gpu.Scene(atrium_small.desc)
+    tri = assert_trace_parity(sc, atrium_small_oracle, rays)
+    assert (tri >= 0).mean() > 0.5
+
+
 def test_deep_tree_uses_the_stack_beyond_lds(gpu):
     """Nested shells of triangles whose sizes fall geometrically give a tall, thin tree; rays
     through the common centre enter every child box on the way down, so the per-lane stack grows
