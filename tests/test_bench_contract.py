@@ -7,9 +7,9 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r03_c_bench_line.json")
-LINE_PROFILED = os.path.join(ROOT, "profiles", "r03_c_bench_line_under_rocprof.json")      # printed while rocprofv3 made STATS
-STATS = os.path.join(ROOT, "profiles", "r03_c_bench_kernel_stats.csv")
+LINE = os.path.join(ROOT, "profiles", "r03_d_bench_line.json")
+LINE_PROFILED = os.path.join(ROOT, "profiles", "r03_d_bench_line_under_rocprof.json")      # printed while rocprofv3 made STATS
+STATS = os.path.join(ROOT, "profiles", "r03_d_bench_kernel_stats.csv")
 
 
 def load_line(path=LINE):
