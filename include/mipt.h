@@ -231,7 +231,11 @@ int mipt_scene_download_bvh(const mipt_scene* scene, uint32_t* nodes, float* tri
  * per ray: origin, direction).  This is the search of TraceRays, PathTracer.cu:
  * 244-288 / CCPUPathTracer::Trace, CPUPathTracer.cpp:251-285, without shading.
  * out_tri[i] = global triangle id or -1; out_tuv = 3 floats per ray (t, ua, va);
- * out_any[i] = 1 if any triangle is hit with t >= 0 (the bHitOnly result). */
+ * out_any[i] = 1 if any triangle is hit with t >= 0 (the bHitOnly result).
+ * The results are those of testing every triangle (no box decides one), as long as the ray starts
+ * within a few hundred scene sizes of the scene: the boxes are tested with a margin of 32 units in
+ * the last place of the ray's reach, and from some thousand scene sizes away the rounding of the
+ * triangle test itself (barycentric coordinates off by 0.1) accepts triangles beyond that margin. */
 int mipt_trace_rays(mipt_scene* scene, const float* rays, int64_t num_rays, float epsilon,
                     int32_t* out_tri, float* out_tuv, uint8_t* out_any);
 
