@@ -17,7 +17,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <chrono>
+#include <utility>
 #include <vector>
 
 #define MAX_BINS 32
@@ -647,6 +649,110 @@ __global__ void __launch_bounds__(256) k_unify_codes(uint4* wide, int64_t numSlo
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The slots that the traversal keeps in LDS.  The collapse hands out slots level by level, so the first
+// MIPT_TRACE_CACHE_SLOTS slots are the top levels of the tree and whatever part of the next level came first.  A ray
+// visits a node with a probability that goes with the surface of its box, so the nodes with the largest boxes are
+// exchanged into those slots (on the headline scene they receive 0.535 of the visits of random rays against 0.508).
+__global__ void __launch_bounds__(256) k_slot_area(const uint4* __restrict__ wide, int64_t numSlots, float cx, float cy, float cz, float* area)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numSlots) return;
+    uint32_t w[4 * MIPT_NODE_U4];
+    for (int k = 0; k < MIPT_NODE_U4; k++) { uint4 q = wide[i * MIPT_NODE_U4 + k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    int lo[3] = { 1 << 20, 1 << 20, 1 << 20 }, hi[3] = { -1, -1, -1 };
+    bool any = false;
+    for (int c = 0; c < MIPT_NODE_WIDTH; c++) {
+        if (w[3 * MIPT_NODE_WIDTH + c] == MIPT_NO_NODE) continue;
+        // a slot that holds no node is all zeros: its "children" have code 0 and empty extent, and count for nothing
+        any = true;
+        for (int a = 0; a < 3; a++) { int l = (int)(w[3 * c + a] & 0xFFFFu), h = (int)(w[3 * c + a] >> 16); lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a]; }
+    }
+    float dx = any ? fmaxf((float)(hi[0] - lo[0]), 0.0f) * cx : 0.0f, dy = any ? fmaxf((float)(hi[1] - lo[1]), 0.0f) * cy : 0.0f, dz = any ? fmaxf((float)(hi[2] - lo[2]), 0.0f) * cz : 0.0f;
+    area[i] = dx * dy + dy * dz + dz * dx;
+}
+__global__ void __launch_bounds__(256) k_remap_identity(uint32_t* remap, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) remap[i] = (uint32_t)i;
+}
+// pairs[i] = (a, b): the nodes in slots a and b change places
+__global__ void __launch_bounds__(256) k_swap_slots(uint4* wide, const uint2* __restrict__ pairs, int n, uint32_t* remap)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * MIPT_NODE_U4) return;
+    const uint2 p = pairs[i / MIPT_NODE_U4];
+    const int k = i % MIPT_NODE_U4;
+    uint4 x = wide[(size_t)p.x * MIPT_NODE_U4 + k], y = wide[(size_t)p.y * MIPT_NODE_U4 + k];
+    wide[(size_t)p.x * MIPT_NODE_U4 + k] = y; wide[(size_t)p.y * MIPT_NODE_U4 + k] = x;
+    if (k == 0) { remap[p.x] = p.y; remap[p.y] = p.x; }
+}
+__global__ void __launch_bounds__(256) k_remap_codes(uint4* wide, int64_t numSlots, const uint32_t* __restrict__ remap)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numSlots) return;
+    auto fix = [&](uint32_t x) { return (x != MIPT_NO_NODE && x < (uint32_t)numSlots) ? remap[x] : x; };      // codes from numSlots on are leaves
+    for (int k = 3 * MIPT_NODE_WIDTH / 4; k < MIPT_NODE_U4; k++) {
+        uint4 c = wide[i * MIPT_NODE_U4 + k];
+        wide[i * MIPT_NODE_U4 + k] = make_uint4(fix(c.x), fix(c.y), fix(c.z), fix(c.w));
+    }
+}
+
+// Called with the finished tree (unified child codes).  Returns MIPT_OK or an error code; the tree stays valid either way
+// up to the point of failure being a HIP error, after which the caller frees it.
+static int promote_large_nodes(BvhResult* out, int64_t topSlots, hipStream_t stream)
+{
+    const int64_t n = out->numNodeSlots;
+    if (n <= topSlots || topSlots <= 0 || getenv("MIPT_BUILD_NO_PROMOTE")) return MIPT_OK;
+    float* dArea = nullptr; uint32_t* dRemap = nullptr; uint2* dPairs = nullptr;
+    std::vector<float> area((size_t)n);
+    std::vector<uint2> pairs;
+    hipError_t e = hipSuccess;
+    auto tryq = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    tryq(hipMalloc(&dArea, sizeof(float) * (size_t)n));
+    tryq(hipMalloc(&dRemap, sizeof(uint32_t) * (size_t)n));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_slot_area, dim3(grid), dim3(256), 0, stream, out->nodes, n, out->qcell[0], out->qcell[1], out->qcell[2], dArea);
+        hipLaunchKernelGGL(k_remap_identity, dim3(grid), dim3(256), 0, stream, dRemap, n);
+        tryq(hipMemcpyAsync(area.data(), dArea, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        tryq(hipStreamSynchronize(stream));
+    }
+    if (e == hipSuccess) {
+        // the topSlots slots of largest area, equal areas by lower slot number: those of them that lie beyond the top
+        // change places with the slots of the top that are not among them
+        std::vector<uint32_t> order((size_t)n);
+        for (int64_t i = 0; i < n; i++) order[(size_t)i] = (uint32_t)i;
+        auto larger = [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
+        std::nth_element(order.begin(), order.begin() + topSlots, order.end(), larger);
+        std::vector<uint8_t> chosen((size_t)topSlots, 0);
+        std::vector<uint32_t> in;
+        for (int64_t i = 0; i < topSlots; i++) { uint32_t s = order[(size_t)i]; if ((int64_t)s < topSlots) chosen[s] = 1; else in.push_back(s); }
+        std::sort(in.begin(), in.end());
+        size_t k = 0;
+        for (int64_t s = 0; s < topSlots && k < in.size(); s++) if (!chosen[(size_t)s]) pairs.push_back(make_uint2(in[k++], (uint32_t)s));
+    }
+    if (e == hipSuccess && !pairs.empty()) {
+        tryq(hipMalloc(&dPairs, sizeof(uint2) * pairs.size()));
+        tryq(hipMemcpyAsync(dPairs, pairs.data(), sizeof(uint2) * pairs.size(), hipMemcpyHostToDevice, stream));
+        if (e == hipSuccess) {
+            const int np = (int)pairs.size();
+            hipLaunchKernelGGL(k_swap_slots, dim3((unsigned)((np * MIPT_NODE_U4 + 255) / 256)), dim3(256), 0, stream, out->nodes, dPairs, np, dRemap);
+            hipLaunchKernelGGL(k_remap_codes, dim3(grid), dim3(256), 0, stream, out->nodes, n, dRemap);
+            uint32_t root = out->rootCode;
+            if (root != MIPT_NO_NODE && root < (uint32_t)n) tryq(hipMemcpyAsync(&root, dRemap + root, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            tryq(hipStreamSynchronize(stream));
+            tryq(hipGetLastError());
+            out->rootCode = root;
+        }
+    }
+    if (dArea) (void)hipFree(dArea);
+    if (dRemap) (void)hipFree(dRemap);
+    if (dPairs) (void)hipFree(dPairs);
+    if (e != hipSuccess) { fprintf(stderr, "bvh build: promoting the largest nodes failed: %s\n", hipGetErrorString(e)); return MIPT_E_DEVICE; }
+    return MIPT_OK;
+}
+
 void mipt_free_bvh(BvhResult* r)
 {
     if (!r) return;
@@ -785,6 +891,12 @@ int mipt_build_bvh(const float4* d_attr, int64_t numTris, const mipt_build_optio
         hipLaunchKernelGGL(k_unify_codes, dim3((unsigned)((out->numNodeSlots + 255) / 256)), dim3(256), 0, stream, out->nodes, out->numNodeSlots, (uint32_t)out->numNodeSlots);
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipGetLastError());
+        {
+            auto t0 = std::chrono::steady_clock::now();
+            rc = promote_large_nodes(out, MIPT_TRACE_CACHE_SLOTS, stream);
+            if (rc) goto done;
+            out->buildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
     }
 done:
     if (primMin) (void)hipFree(primMin);

@@ -30,6 +30,9 @@
 #define MIPT_NODE_U4 MIPT_NODE_WIDTH   // uint4 per node slot
 #define MIPT_STACK_LDS_MAX 16   // stack rows (4 bytes per lane) kept in LDS (4 KiB per wave), the two bottom rows that mark the end of every lane's stack included; deeper rows, which one node step in two hundred needs, go to the spill slice
 #define MIPT_SHADE_F4 8
+// Node slots of the top of the array that every traversal workgroup copies into LDS (32 KiB).  The builder puts the
+// nodes with the largest boxes, which the most rays visit, into these slots.
+#define MIPT_TRACE_CACHE_SLOTS 512
 // A queue in blocks: entries [b << MIPT_QBLOCK_SHIFT, (b << MIPT_QBLOCK_SHIFT) + blockCount[b]) of every block b are valid
 #define MIPT_QBLOCK_SHIFT 10
 #define MIPT_LEAF_BIT 0x80000000u   // marks leaves in the binary tree the builder works on; the finished tree uses leafBase

@@ -165,7 +165,7 @@ void launch_unpack_hits(const float4* hit, int64_t n, int32_t* d_outTri, float* 
 #define TRACE_CHUNK 256
 #define TRACE_CHUNK_SHADOW 512
 #define TRACE_WAVES 12            // waves per workgroup
-#define TRACE_CACHE_SLOTS 512     // node slots copied to LDS per workgroup (32 KiB)
+#define TRACE_CACHE_SLOTS MIPT_TRACE_CACHE_SLOTS     // node slots copied to LDS per workgroup (32 KiB)
 #define TRACE_TRI_VOTE 12
 #define TRACE_NODE_DROP 24
 #define TRACE_REFILL_MIN 1     // idle lanes a wave waits for before it hands out new rays
