@@ -75,6 +75,9 @@ def main():
         "octant bins, stable": np.argsort(octant, kind="stable"),
         "octant bins within blocks of 1M slots": np.lexsort((octant, slot >> 20)),
         "octant bins within blocks of 64k slots": np.lexsort((octant, slot >> 16)),
+        "octant bins within blocks of 1024 slots": np.lexsort((octant, slot >> 10)),
+        "dir 8^3 cell within blocks of 1024 slots": np.lexsort((dkey, slot >> 10)),
+        "dir 8^3 cell within blocks of 16k slots": np.lexsort((dkey, slot >> 14)),
         "octant, then origin morton": np.lexsort((mort, octant)),
         "dir 8^3 cell, then origin morton": np.lexsort((mort, dkey)),
         "origin morton, then octant": np.lexsort((octant, mort)),
