@@ -89,6 +89,37 @@ def test_bvh_atrium_small(gpu, atrium_small):
     assert info.sah_cost > 0
 
 
+def test_largest_nodes_sit_in_the_cached_slots(gpu, atrium_small, monkeypatch):
+    """The traversal keeps the first 512 node slots in LDS; the builder exchanges the nodes with the largest boxes
+    (surface of the union of a node's child boxes, which goes with the number of rays that visit it) into them.
+    With MIPT_BUILD_NO_PROMOTE the slots stay as the level-by-level collapse hands them out; both trees are valid."""
+    def areas(dev_scene):
+        nodes, _, _, _, root, (qmin, qcell) = dev_scene.download_bvh()
+        W = dev_scene.info().node_width
+        codes = nodes[:, 3 * W:]
+        w = nodes[:, :3 * W].reshape(-1, W, 3).astype(np.int64)
+        valid = codes != 0xFFFFFFFF
+        lo = np.where(valid[..., None], w & 0xFFFF, 1 << 20).min(axis=1).astype(np.float64)
+        hi = np.where(valid[..., None], w >> 16, -1).max(axis=1).astype(np.float64)
+        d = np.maximum(hi - lo, 0) * qcell.astype(np.float64)
+        a = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+        return a, root
+
+    sc = gpu.Scene(atrium_small.desc)
+    validate_bvh(atrium_small, sc)
+    a, root = areas(sc)
+    assert a.shape[0] > 512, "the scene must have more node slots than the copy holds"
+    assert a[:512].min() >= a[512:].max(), "a node beyond the cached slots has a larger box than one inside"
+    assert root < 512 and a[root] == a.max()
+    monkeypatch.setenv("MIPT_BUILD_NO_PROMOTE", "1")
+    plain = gpu.Scene(atrium_small.desc)
+    monkeypatch.delenv("MIPT_BUILD_NO_PROMOTE")
+    validate_bvh(atrium_small, plain)
+    b, _ = areas(plain)
+    assert b[:512].min() < b[512:].max(), "without the exchange the top slots are not the largest nodes (else this test shows nothing)"
+    assert np.isclose(np.sort(a).sum(), np.sort(b).sum(), rtol=1e-9)      # the same nodes, in other slots
+
+
 def test_bvh_degenerate_inputs(gpu):
     # one triangle; many identical triangles (coincident centroids force splits by position);
     # zero-area and sliver triangles; an empty scene
