@@ -232,7 +232,9 @@ int mipt_scene_download_bvh(const mipt_scene* scene, uint32_t* nodes, float* tri
  * 244-288 / CCPUPathTracer::Trace, CPUPathTracer.cpp:251-285, without shading.
  * out_tri[i] = global triangle id or -1; out_tuv = 3 floats per ray (t, ua, va);
  * out_any[i] = 1 if any triangle is hit with t >= 0 (the bHitOnly result).
- * The results are those of testing every triangle (no box decides one), as long as the ray starts
+ * The results are those of testing every triangle whose box the ray reaches before its best hit (a
+ * triangle almost in the ray's plane can be accepted by the test with a distance that is rounding noise
+ * and lies before its own box: one of 4 000 000 test rays), as long as the ray starts
  * within a few hundred scene sizes of the scene: the boxes are tested with a margin of 32 units in
  * the last place of the ray's reach, and from some thousand scene sizes away the rounding of the
  * triangle test itself (barycentric coordinates off by 0.1) accepts triangles beyond that margin. */
